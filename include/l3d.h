@@ -1,0 +1,183 @@
+/*
+ * l3d.h -- C ABI of the MI355X (gfx950) stereo-depth + laser centre-line library
+ * (libl3d_hip.so).  Every entry point is extern "C", takes plain pointers and
+ * sizes, returns 0 on success or a negative l3d_status, and never throws; the
+ * text of the last error on the calling thread is available from
+ * l3d_last_error().
+ *
+ * The reference project has no FFI of its own: its hot path is a sequence of
+ * calls into the OpenCV / NumPy wheels.  Each entry point below therefore cites
+ * the reference call site (file:line under the reference repository) whose
+ * third-party call it replaces.
+ *
+ * Conventions
+ *   - "host" entry points take caller-owned host buffers and copy in/out.
+ *   - "_device" entry points take device pointers that are already resident in
+ *     HBM ([batch][H][W] contiguous) and enqueue on `stream` (a hipStream_t
+ *     passed as void*; NULL = the handle's own stream).  They do not
+ *     synchronise; the host variants do.
+ *   - A handle owns all scratch memory it needs (allocated at create time for
+ *     `max_batch` frames) and one stream.  A handle is not thread-safe; distinct
+ *     handles are independent.
+ *   - Images are single-channel u8 unless stated; disparities are int16 fixed
+ *     point with 4 fractional bits, exactly as cv2.StereoSGBM.compute returns.
+ */
+#ifndef L3D_H
+#define L3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    L3D_OK = 0,
+    L3D_ERR_INVALID_ARG = -1,
+    L3D_ERR_UNSUPPORTED = -2,
+    L3D_ERR_HIP = -3,
+    L3D_ERR_NO_DEVICE = -4,
+    L3D_ERR_CAPACITY = -5
+} l3d_status;
+
+const char *l3d_last_error(void);
+const char *l3d_version(void);
+/* number of visible HIP devices (0 and L3D_ERR_NO_DEVICE when there is none) */
+int l3d_device_count(int *n);
+
+/* ---------------------------------------------------------------------------
+ * Semi-global block matching, cv2.STEREO_SGBM_MODE_SGBM_3WAY semantics.
+ * Field names and meaning are cv2.StereoSGBM_create's keyword arguments
+ * (camera/single_usb_stereo_camera.py:252-274).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int minDisparity;
+    int numDisparities;    /* multiple of 32 on this build (64 / 96 / 128 ...) */
+    int blockSize;         /* odd, 1..21 */
+    int P1, P2;
+    int disp12MaxDiff;
+    int preFilterCap;
+    int uniquenessRatio;
+    int speckleWindowSize;
+    int speckleRange;
+    int mode;              /* 2 = cv2.STEREO_SGBM_MODE_SGBM_3WAY (only mode built) */
+} l3d_sgbm_params;
+
+typedef struct l3d_sgbm l3d_sgbm;
+
+/* replaces cv2.StereoSGBM_create(...) (camera/single_usb_stereo_camera.py:252)
+ * and cv2.ximgproc.createRightMatcher's product (:277) */
+int l3d_sgbm_create(const l3d_sgbm_params *params, int width, int height, int max_batch, int device,
+                    l3d_sgbm **out);
+void l3d_sgbm_destroy(l3d_sgbm *h);
+
+/* replaces stereo_matcher.compute(left_gray, right_gray)
+ * (camera/single_usb_stereo_camera.py:324-325).  Host buffers; row_stride and
+ * img_stride in bytes; disp is [batch][H][W] int16, contiguous. */
+int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int batch,
+                     ptrdiff_t row_stride, ptrdiff_t img_stride, int16_t *disp);
+/* same, device-resident operands */
+int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch,
+                            int16_t *d_disp, void *stream);
+
+/* Stage buffers of the most recent compute on this handle, copied to host
+ * after synchronising (for stage-level parity checks):
+ *   0 = aggregated BT cost C      [batch][H][W1][D] int16
+ *   1 = top->down path L          [batch][H][W1][D] int16
+ *   2 = disparity before median   [batch][H][W]     int16
+ * bytes must not exceed the stage's size for the last batch. */
+int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size_t bytes);
+/* out8 = {minX1, W1, stripe_sz, stripe_overlap, invalid16, ftzero, P1, P2} */
+int l3d_sgbm_geometry(const l3d_sgbm_params *params, int width, int height, int *out8);
+
+/* ---------------------------------------------------------------------------
+ * cv2.ximgproc.DisparityWLSFilter (confidence + fast global smoother).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    double lambda;        /* wls_filter.setLambda  (camera/...:281), reference 8000 */
+    double sigma_color;   /* wls_filter.setSigmaColor (:282), reference 1.5 */
+    int min_disparity;    /* of the left matcher */
+    int num_disparities;
+    int lrc_thresh;       /* 24 */
+    int disc_radius;      /* ceil(0.5 * blockSize) */
+    float disc_rolloff;   /* 0.001 */
+    int fgs_iters;        /* 3 */
+    float fgs_attenuation;/* 0.25 */
+} l3d_wls_params;
+
+typedef struct l3d_wls l3d_wls;
+
+/* replaces cv2.ximgproc.createDisparityWLSFilter(left_matcher) + setLambda +
+ * setSigmaColor (camera/single_usb_stereo_camera.py:280-282) */
+int l3d_wls_create(const l3d_wls_params *params, int width, int height, int max_batch, int device,
+                   l3d_wls **out);
+void l3d_wls_destroy(l3d_wls *h);
+/* replaces wls_filter.filter(dL, left_gray, disparity_map_right=dR) (:328-332) */
+int l3d_wls_filter(l3d_wls *h, const int16_t *disp_left, const int16_t *disp_right, const uint8_t *guide,
+                   int batch, int16_t *out);
+int l3d_wls_filter_device(l3d_wls *h, const int16_t *d_disp_left, const int16_t *d_disp_right,
+                          const uint8_t *d_guide, int batch, int16_t *d_out, void *stream);
+/* confidence map (x255) of the most recent filter call, [batch][H][W] float */
+int l3d_wls_fetch_confidence(l3d_wls *h, float *host_dst, size_t bytes);
+
+/* ---------------------------------------------------------------------------
+ * Colour conversion + disparity -> depth.
+ * ------------------------------------------------------------------------- */
+/* replaces cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
+ * (camera/single_usb_stereo_camera.py:320-321).  [batch][H][W][3] -> [batch][H][W] */
+int l3d_bgr2gray_device(const uint8_t *d_bgr, int width, int height, int batch, uint8_t *d_gray,
+                        int device, void *stream);
+int l3d_bgr2gray(const uint8_t *bgr, int width, int height, int batch, uint8_t *gray, int device);
+
+/* replaces `.astype(float32)/16`, cv2.reprojectImageTo3D(disparity, Q)[:,:,2] and
+ * the three validity masks (camera/single_usb_stereo_camera.py:335-346); with
+ * Q == NULL the uncalibrated fallback of :349-357.  depth [batch][H][W] float;
+ * xyz (may be NULL, needs Q) [batch][H][W][3] float = unmasked
+ * reprojectImageTo3D output. */
+int l3d_depth_from_disp16_device(const int16_t *d_disp16, const double *Q16_host, int width, int height,
+                                 int batch, float *d_depth, float *d_xyz, int device, void *stream);
+int l3d_depth_from_disp16(const int16_t *disp16, const double *Q16, int width, int height, int batch,
+                          float *depth, float *xyz, int device);
+
+/* ---------------------------------------------------------------------------
+ * Steger ridge extractor (FastStegerExtractor, core/laser_extractor.py:103-261).
+ * ------------------------------------------------------------------------- */
+typedef struct l3d_steger l3d_steger;
+
+/* replaces FastStegerExtractor.__init__ (core/laser_extractor.py:109-136) */
+int l3d_steger_create(double sigma, int brightness_threshold, int max_width, int max_height,
+                      int max_batch, int device, l3d_steger **out);
+void l3d_steger_destroy(l3d_steger *h);
+/* replaces FastStegerExtractor.extract_centerline / extract_batch
+ * (core/laser_extractor.py:160-261, 279-285): cv2.cvtColor + GaussianBlur +
+ * 5 x filter2D + per-pixel np.linalg.eig loop.
+ * img: [batch][H][W][channels] u8, channels 1 or 3 (BGR); roi = {x,y,w,h} or NULL.
+ * xy: [batch][capacity][2] float (x, y), raster order; counts[batch] receives the
+ * number of points found per image (if > capacity only the first `capacity` are
+ * stored and L3D_ERR_CAPACITY is returned). */
+int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch,
+                       const int *roi, float *xy, int capacity, int *counts);
+/* device operands; d_xy [batch][capacity][2] float, d_counts [batch] int */
+int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, int channels, int width, int height,
+                              int batch, const int *roi, float *d_xy, int capacity, int *d_counts,
+                              void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Laser pixel -> 3-D (Reconstructor, core/reconstruction.py).
+ * ------------------------------------------------------------------------- */
+/* replaces Reconstructor.reconstruct_from_depth (core/reconstruction.py:145-182).
+ * uv: n (u,v) doubles; depth [H][W] float; K row-major 3x3; xyz n*3 doubles
+ * (first *n_out rows valid, input order kept). */
+int l3d_reconstruct_from_depth(const double *uv, int n, const float *depth, int width, int height,
+                               const double *K9, double *xyz, int *n_out, int device);
+/* replaces Reconstructor.reconstruct_point / _refraction_correction /
+ * reconstruct_laser_line (core/reconstruction.py:30-143).  xyz n*3 doubles, rows
+ * of NaN where the reference returns NaN. */
+int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv9, const double *plane4,
+                          int refraction, double n_water, double *xyz, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L3D_H */

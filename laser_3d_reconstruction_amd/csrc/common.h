@@ -1,0 +1,49 @@
+// Shared host-side helpers of libl3d_hip.so: error reporting and launch checks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <cstddef>
+#include "../../include/l3d.h"
+
+namespace l3d {
+
+// thread-local error text behind l3d_last_error()
+void set_error(const char *fmt, ...);
+
+#define L3D_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            ::l3d::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return L3D_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define L3D_REQUIRE(cond, ...)                                                                     \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            ::l3d::set_error(__VA_ARGS__);                                                         \
+            return L3D_ERR_INVALID_ARG;                                                            \
+        }                                                                                          \
+    } while (0)
+
+// Selects `device` for the lifetime of the object and restores the previous one.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace l3d

@@ -1,0 +1,797 @@
+// Semi-global block matching (cv2.STEREO_SGBM_MODE_SGBM_3WAY semantics) for gfx950.
+//
+// Replaces stereo_matcher.compute / right_matcher.compute of the reference
+// (camera/single_usb_stereo_camera.py:252-277, 324-325).
+//
+// Data layout in HBM (per handle, sized for max_batch frames):
+//   lrec   [B][H][W]      uint2   left image, per pixel: Sobel-clipped gradient value and its
+//                                 Birchfield-Tomasi half-pixel min/max, raw intensity and its min/max
+//   rrev   [B][6][H][W]   u8      the same six quantities of the right image as separate planes,
+//                                 mirrored in x so that increasing disparity = increasing address
+//   Cvol   [B][H][W1][D]  s16     block-aggregated matching cost of the stripe that owns the row
+//   Tvol   [B][H][W1][D]  s16     top->down path cost
+//   Lvol   [B][H][W1][D]  s16     left->right path cost, overwritten by nothing else
+//   wta    [B][H][W1]     u32     (biased min S << 16 | argmin) or 0xFFFFFFFF (uniqueness reject)
+//   dsub   [B][H][W1]     s16     sub-pixel disparity (x16) of the column
+//   raw    [B][H][W]      s16     disparity after the left-right check
+//   med    [B][H][W]      s16     after the 3x3 median (speckle filter runs in place on the output)
+//   labels [B][H][W]      s32     union-find parents of the speckle filter, sizes [B][H][W] s32
+//
+// Work decomposition: a disparity vector of one pixel lives in one DPP row (16 lanes); each lane
+// holds 2*NP consecutive disparities as NP packed int16 pairs (D = 32*NP), so the d-1 / d+1
+// neighbours of the SGM recurrence are one row_shr / row_shl DPP move plus v_alignbit, the
+// min over d is a 4-step row_ror butterfly, and all cost arithmetic is v_pk_*_i16 with the
+// clamp bit (the 16-bit saturating arithmetic the recurrence is defined in).  A 64-lane wave
+// therefore carries 4 independent pixels: 4 image columns in the vertical kernel, 4 image rows
+// in the horizontal kernel.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace l3d {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+struct SgbmGeom {
+    int W, H, minD, D, SW2, SH2, P1, P2, uniq, disp12MaxDiff, ftzero;
+    int minX1, maxX1, W1, invalid16;
+    int stripe_sz, stripe_overlap;
+    int speckleWindowSize, speckleRange;
+    int NP; // packed pairs per lane, D = 32 * NP
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t as_u32(v2s a) { return __builtin_bit_cast(uint32_t, a); }
+__device__ __forceinline__ v2s as_v2s(uint32_t a) { return __builtin_bit_cast(v2s, a); }
+__device__ __forceinline__ uint32_t as_u32u(v2u a) { return __builtin_bit_cast(uint32_t, a); }
+__device__ __forceinline__ v2u as_v2u(uint32_t a) { return __builtin_bit_cast(v2u, a); }
+
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_v2s(a), as_v2s(b))); }
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_add_sat(as_v2s(a), as_v2s(b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_sub_sat(as_v2s(a), as_v2s(b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u32(as_v2s(a) + as_v2s(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_v2s(a) - as_v2s(b)); }
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, int s) { v2s m = {(short)s, (short)s}; return as_u32(as_v2s(a) * m); }
+__device__ __forceinline__ uint32_t pk_splat(int s) { return ((uint32_t)s & 0xffffu) * 0x10001u; }
+// unsigned 16-bit packed helpers for the Birchfield-Tomasi cost
+__device__ __forceinline__ uint32_t pku_subs(uint32_t a, uint32_t b) { return as_u32u(__builtin_elementwise_sub_sat(as_v2u(a), as_v2u(b))); }
+__device__ __forceinline__ uint32_t pku_max(uint32_t a, uint32_t b) { return as_u32u(__builtin_elementwise_max(as_v2u(a), as_v2u(b))); }
+__device__ __forceinline__ uint32_t pku_min(uint32_t a, uint32_t b) { return as_u32u(__builtin_elementwise_min(as_v2u(a), as_v2u(b))); }
+
+// DPP moves inside a row of 16 lanes.  Lanes without a source keep `fill`.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t fill, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)src, CTRL, 0xf, 0xf, false);
+}
+#define DPP_ROW_SHL1 0x101 // lane i <- lane i+1
+#define DPP_ROW_SHR1 0x111 // lane i <- lane i-1
+#define DPP_ROW_ROR1 0x121
+#define DPP_ROW_ROR2 0x122
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+
+// all-lanes minimum of a u32 over the 16 lanes of a DPP row
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
+{
+    v = min(v, dpp_row<DPP_ROW_ROR8>(v, v));
+    v = min(v, dpp_row<DPP_ROW_ROR4>(v, v));
+    v = min(v, dpp_row<DPP_ROW_ROR2>(v, v));
+    v = min(v, dpp_row<DPP_ROW_ROR1>(v, v));
+    return v;
+}
+// all-lanes minimum over both halves of a packed int16 pair across the row; returns the scalar
+__device__ __forceinline__ int row_min_pk(uint32_t v)
+{
+    v = pk_min(v, dpp_row<DPP_ROW_ROR8>(v, v));
+    v = pk_min(v, dpp_row<DPP_ROW_ROR4>(v, v));
+    v = pk_min(v, dpp_row<DPP_ROW_ROR2>(v, v));
+    v = pk_min(v, dpp_row<DPP_ROW_ROR1>(v, v));
+    v2s p = as_v2s(v);
+    return min((int)p.x, (int)p.y);
+}
+
+template <int NP>
+struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : 4))) Pack {
+    uint32_t v[NP];
+};
+
+// One step of the SGM recurrence on a disparity vector spread over a DPP row:
+//   out[d] = C[d] + min(prev[d], prev[d-1]+P1, prev[d+1]+P1, prevMin+P2) - (prevMin+P2)
+// in saturating int16 arithmetic.  `st` holds prev on entry and out on return; returns min_d out.
+template <int NP>
+__device__ __forceinline__ int sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[NP], int prevMin, uint32_t P1v, int P2)
+{
+    const uint32_t BIG = 0x7fff7fffu;
+    int mp2 = prevMin + P2;
+    mp2 = mp2 > 32767 ? 32767 : mp2;
+    const uint32_t mp2v = pk_splat(mp2);
+    const uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
+    const uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, st[0]);      // lane+1's bottom pair
+    uint32_t out[NP];
+    uint32_t mn = BIG;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const uint32_t lo_src = (p > 0) ? st[p - 1] : below;
+        const uint32_t hi_src = (p < NP - 1) ? st[p + 1] : above;
+        const uint32_t dm1 = __builtin_amdgcn_alignbit(st[p], lo_src, 16); // (prev[d-1]) for both halves
+        const uint32_t dp1 = __builtin_amdgcn_alignbit(hi_src, st[p], 16); // (prev[d+1])
+        const uint32_t a = pk_adds(pk_min(dm1, dp1), P1v);
+        const uint32_t m = pk_min(a, pk_min(st[p], mp2v));
+        out[p] = pk_adds(c[p], pk_subs(m, mp2v));
+        mn = pk_min(mn, out[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) st[p] = out[p];
+    return row_min_pk(mn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: x-Sobel prefilter + Birchfield-Tomasi half-pixel min/max for both images
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void prefilter_px(const uint8_t *img, int W, int H, int y, int x, int ftzero, int &grad, int &raw)
+{
+    if (x <= 0 || x >= W - 1) { grad = ftzero; raw = ftzero; return; }
+    const uint8_t *r0 = img + (size_t)y * W;
+    const uint8_t *rn = y > 0 ? r0 - W : r0;
+    const uint8_t *rs = y < H - 1 ? r0 + W : r0;
+    int s = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + (int)rn[x + 1] - (int)rn[x - 1] + (int)rs[x + 1] - (int)rs[x - 1];
+    s = s < -ftzero ? -ftzero : (s > ftzero ? ftzero : s);
+    grad = s + ftzero;
+    raw = r0[x];
+}
+
+__global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
+                                                   int W, int H, int ftzero, uint2 *__restrict__ lrec, uint8_t *__restrict__ rrev)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const size_t img_off = (size_t)b * W * H;
+    for (int side = 0; side < 2; side++) {
+        const uint8_t *img = (side == 0 ? left : right) + img_off;
+        int gm, rm, gc, rc, gp, rp;
+        prefilter_px(img, W, H, y, x, ftzero, gc, rc);
+        if (x > 0) prefilter_px(img, W, H, y, x - 1, ftzero, gm, rm); else { gm = gc; rm = rc; }
+        if (x < W - 1) prefilter_px(img, W, H, y, x + 1, ftzero, gp, rp); else { gp = gc; rp = rc; }
+        const int gl = x > 0 ? (gc + gm) / 2 : gc, gr = x < W - 1 ? (gc + gp) / 2 : gc;
+        const int rl = x > 0 ? (rc + rm) / 2 : rc, rr = x < W - 1 ? (rc + rp) / 2 : rc;
+        const int glo = min(gc, min(gl, gr)), ghi = max(gc, max(gl, gr));
+        const int rlo = min(rc, min(rl, rr)), rhi = max(rc, max(rl, rr));
+        if (side == 0) {
+            lrec[img_off + (size_t)y * W + x] = make_uint2((uint32_t)(gc | (glo << 8) | (ghi << 16)), (uint32_t)(rc | (rlo << 8) | (rhi << 16)));
+        } else {
+            const size_t plane = (size_t)W * H;
+            uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - x);
+            o[0] = (uint8_t)gc; o[plane] = (uint8_t)glo; o[2 * plane] = (uint8_t)ghi;
+            o[3 * plane] = (uint8_t)rc; o[4 * plane] = (uint8_t)rlo; o[5 * plane] = (uint8_t)rhi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: pixel cost -> box aggregation -> top->down path, one block per (16 columns, stripe, frame)
+// ---------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void load_bytes(const uint8_t *p, uint8_t (&dst)[2 * NP])
+{
+    __builtin_memcpy(dst, p, 2 * NP);
+}
+
+// Birchfield-Tomasi cost of one channel for a packed pair of disparities
+__device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1)
+{
+    const uint32_t c0 = pku_max(pku_subs(u, v1), pku_subs(v0, u));
+    const uint32_t c1 = pku_max(pku_subs(v, u1), pku_subs(u0, v));
+    return pku_min(c0, c1);
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
+                                                       uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol)
+{
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x, grp = tid >> 4, l = tid & 15;
+    const int n = blockIdx.y, b = blockIdx.z;
+    const int W = g.W, H = g.H, W1 = g.W1, SW2 = g.SW2, SH2 = g.SH2;
+    const int start = max(min(n * g.stripe_sz - g.stripe_overlap, H), 0);
+    const int end = min((n + 1) * g.stripe_sz, H);
+    const int own0 = n * g.stripe_sz;
+    if (start >= end) return;
+    const int NR = 2 * SH2 + 2;
+    const int tileC = 16 + 2 * SW2;
+    uint32_t *pixT = smem;                    // [tileC][16][NP]
+    uint32_t *ring = smem + tileC * 16 * NP;  // [NR][256][NP], thread-private slots
+    const int xa = blockIdx.x * 16;
+    const int xc_own = xa + grp;
+    const bool active = xc_own < W1;
+    const size_t plane = (size_t)W * H;
+    const uint2 *lrec_b = lrec + (size_t)b * plane;
+    const uint8_t *rrev_b = rrev + (size_t)b * 6 * plane;
+    const uint32_t P1v = pk_splat(min(g.P1, 32767));
+
+    uint32_t Cst[NP], Tst[NP], hs[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = 0; }
+    int topMin = 0;
+
+    // horizontal box sum of the pixel costs of image row k for this thread's column / disparities
+    auto compute_hs = [&](int k) {
+        __syncthreads();
+        for (int c = grp; c < tileC; c += 16) {
+            int xc = xa - SW2 + c;
+            xc = xc < 0 ? 0 : (xc > W1 - 1 ? W1 - 1 : xc);
+            const int x = xc + g.minX1;
+            const uint2 lr = lrec_b[(size_t)k * W + x];
+            const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
+            const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
+            const uint8_t *rp = rrev_b + (size_t)k * W + (W - 1 - x + g.minD + l * 2 * NP);
+            uint8_t q[6][2 * NP];
+#pragma unroll
+            for (int j = 0; j < 6; j++) load_bytes<NP>(rp + j * plane, q[j]);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                uint32_t v[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v[j] = (uint32_t)q[j][2 * p] | ((uint32_t)q[j][2 * p + 1] << 16);
+                const uint32_t cg = bt_pair(u, u0, u1, v[0], v[1], v[2]);
+                const uint32_t ci = bt_pair(t, t0, t1, v[3], v[4], v[5]);
+                pixT[(c * 16 + l) * NP + p] = cg + ((ci >> 2) & 0x3fff3fffu);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; p++) hs[p] = 0;
+        for (int j = 0; j <= 2 * SW2; j++) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], pixT[((grp + j) * 16 + l) * NP + p]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++) ring[((k % NR) * 256 + tid) * NP + p] = hs[p];
+    };
+
+    // cost of the stripe's first row: rows above it replicate that row
+    for (int k = start; k <= start + SH2; k++) {
+        const int kk = min(k, H - 1);
+        compute_hs(kk);
+        const int scale = (k == start) ? SH2 + 1 : 1;
+#pragma unroll
+        for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pk_mul(hs[p], scale));
+    }
+
+    uint32_t *Cout = Cvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
+    uint32_t *Tout = Tvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
+    for (int y = start; y < end; y++) {
+        topMin = sgm_step<NP>(Cst, Tst, topMin, P1v, g.P2);
+        if (y >= own0 && active) {
+            Pack<NP> pc, pt;
+#pragma unroll
+            for (int p = 0; p < NP; p++) { pc.v[p] = Cst[p]; pt.v[p] = Tst[p]; }
+            const size_t off = (size_t)y * W1 * (size_t)(16 * NP);
+            *reinterpret_cast<Pack<NP> *>(Cout + off) = pc;
+            *reinterpret_cast<Pack<NP> *>(Tout + off) = pt;
+        }
+        if (y + 1 < end) {
+            const int kadd = y + 1 + SH2;
+            if (kadd <= H - 1) {
+                compute_hs(kadd);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; p++) hs[p] = ring[(((H - 1) % NR) * 256 + tid) * NP + p];
+            }
+            const int ksub = max(y - SH2, start);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t sub = ring[((ksub % NR) * 256 + tid) * NP + p];
+                Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: left->right pass (writes Lvol), then right->left pass + sum + WTA / uniqueness / sub-pixel.
+// One DPP row (16 lanes) per image row; a 64-thread block covers 4 consecutive rows.
+// ---------------------------------------------------------------------------------------------
+template <int NP>
+__global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
+                                                   const uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Lvol,
+                                                   uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
+{
+    const int tid = threadIdx.x, grp = tid >> 4, l = tid & 15;
+    const int row = blockIdx.x * 4 + grp;
+    if (row >= nrows_total) return;
+    const int W1 = g.W1;
+    const size_t rs = (size_t)(16 * NP);            // u32 per column
+    const size_t base = (size_t)row * W1 * rs + l * NP;
+    const uint32_t *Cp = Cvol + base;
+    const uint32_t *Tp = Tvol + base;
+    uint32_t *Lp = Lvol + base;
+    const uint32_t P1v = pk_splat(min(g.P1, 32767));
+
+    uint32_t st[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) st[p] = 0;
+    int mn = 0;
+#pragma unroll 4
+    for (int xc = 0; xc < W1; xc++) {
+        const Pack<NP> c = *reinterpret_cast<const Pack<NP> *>(Cp + xc * rs);
+        mn = sgm_step<NP>(c.v, st, mn, P1v, g.P2);
+        Pack<NP> o;
+#pragma unroll
+        for (int p = 0; p < NP; p++) o.v[p] = st[p];
+        *reinterpret_cast<Pack<NP> *>(Lp + xc * rs) = o;
+    }
+
+#pragma unroll
+    for (int p = 0; p < NP; p++) st[p] = 0;
+    mn = 0;
+    const int d0 = l * 2 * NP; // first disparity index held by this lane
+#pragma unroll 2
+    for (int xc = W1 - 1; xc >= 0; xc--) {
+        const Pack<NP> c = *reinterpret_cast<const Pack<NP> *>(Cp + xc * rs);
+        const Pack<NP> lf = *reinterpret_cast<const Pack<NP> *>(Lp + xc * rs);
+        const Pack<NP> tp = *reinterpret_cast<const Pack<NP> *>(Tp + xc * rs);
+        mn = sgm_step<NP>(c.v, st, mn, P1v, g.P2);
+        uint32_t S[NP];
+        uint32_t key = 0xffffffffu;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            S[p] = pk_adds(pk_adds(st[p], lf.v[p]), tp.v[p]);
+            const v2s s2 = as_v2s(S[p]);
+            const uint32_t k0 = ((uint32_t)((int)s2.x + 32768) << 16) | (uint32_t)(d0 + 2 * p);
+            const uint32_t k1 = ((uint32_t)((int)s2.y + 32768) << 16) | (uint32_t)(d0 + 2 * p + 1);
+            key = min(key, min(k0, k1));
+        }
+        key = row_min_u32(key);
+        const int best = (int)(key & 0xffffu);
+        const int minS = (int)(key >> 16) - 32768;
+        bool reject = false;
+        if (g.uniq > 0) {
+            bool bad = false;
+            const int lim = minS * 100, f = 100 - g.uniq;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const v2s s2 = as_v2s(S[p]);
+                const int da = d0 + 2 * p, db = da + 1;
+                bad |= ((int)s2.x * f < lim) && (abs(da - best) > 1);
+                bad |= ((int)s2.y * f < lim) && (abs(db - best) > 1);
+            }
+            const unsigned long long bal = __ballot(bad);
+            reject = ((bal >> (grp * 16)) & 0xffffull) != 0;
+        }
+        // S shifted by one disparity in both directions, for the parabola fit on the owning lane
+        const uint32_t below = dpp_row<DPP_ROW_SHR1>(0u, S[NP - 1]);
+        const uint32_t above = dpp_row<DPP_ROW_SHL1>(0u, S[0]);
+        if (best >= d0 && best < d0 + 2 * NP) {
+            uint32_t out_w = 0xffffffffu;
+            int dval = 0;
+            if (!reject) {
+                int sc = 0, sm = 0, sp = 0;
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    const uint32_t lo_src = (p > 0) ? S[p - 1] : below;
+                    const uint32_t hi_src = (p < NP - 1) ? S[p + 1] : above;
+                    const v2s cur = as_v2s(S[p]);
+                    const v2s dm1 = as_v2s(__builtin_amdgcn_alignbit(S[p], lo_src, 16));
+                    const v2s dp1 = as_v2s(__builtin_amdgcn_alignbit(hi_src, S[p], 16));
+                    if (best == d0 + 2 * p) { sc = cur.x; sm = dm1.x; sp = dp1.x; }
+                    if (best == d0 + 2 * p + 1) { sc = cur.y; sm = dm1.y; sp = dp1.y; }
+                }
+                int dd;
+                if (0 < best && best < g.D - 1) {
+                    const int denom2 = max(sm + sp - 2 * sc, 1);
+                    dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+                } else
+                    dd = best * 16;
+                dval = dd + g.minD * 16;
+                out_w = key;
+            }
+            wta[(size_t)row * W1 + xc] = out_w;
+            dsub[(size_t)row * W1 + xc] = (int16_t)dval;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: single-map left-right consistency check; one block per image row
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__restrict__ wta, const int16_t *__restrict__ dsub,
+                                                 int16_t *__restrict__ raw)
+{
+    extern __shared__ uint32_t key2[]; // [W]
+    const int row = blockIdx.x; // over B*H
+    const int W = g.W, W1 = g.W1;
+    const uint32_t *w = wta + (size_t)row * W1;
+    const int16_t *ds = dsub + (size_t)row * W1;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) key2[x] = 0xffffffffu;
+    __syncthreads();
+    for (int xc = threadIdx.x; xc < W1; xc += blockDim.x) {
+        const uint32_t k = w[xc];
+        if (k == 0xffffffffu) continue;
+        const int best = (int)(k & 0xffffu);
+        const uint32_t cost = k >> 16;          // biased by 32768
+        if (cost == 65535u) continue;           // a cost of SHRT_MAX never beats the initial SHRT_MAX
+        const int x2 = xc + g.minX1 - best - g.minD;
+        if (x2 >= 0 && x2 < W) atomicMin(&key2[x2], (cost << 16) | (uint32_t)(0xffff - xc));
+    }
+    __syncthreads();
+    int16_t *out = raw + (size_t)row * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int val = g.invalid16;
+        if (x >= g.minX1 && x < g.maxX1) {
+            const int xc = x - g.minX1;
+            if (w[xc] != 0xffffffffu) {
+                const int d1 = ds[xc];
+                val = d1;
+                if (d1 != g.invalid16) {
+                    const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+                    const int _x = x - _d, x_ = x - d_;
+                    bool c1 = false, c2 = false;
+                    if (_x >= 0 && _x < W) {
+                        const uint32_t k = key2[_x];
+                        const int v = (k == 0xffffffffu) ? g.invalid16 : (int)(w[0xffff - (int)(k & 0xffffu)] & 0xffffu) + g.minD;
+                        c1 = v >= g.minD && abs(v - _d) > g.disp12MaxDiff;
+                    }
+                    if (x_ >= 0 && x_ < W) {
+                        const uint32_t k = key2[x_];
+                        const int v = (k == 0xffffffffu) ? g.invalid16 : (int)(w[0xffff - (int)(k & 0xffffu)] & 0xffffu) + g.minD;
+                        c2 = v >= g.minD && abs(v - d_) > g.disp12MaxDiff;
+                    }
+                    if (c1 && c2) val = g.invalid16;
+                }
+            }
+        }
+        out[x] = (int16_t)val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: 3x3 median of int16 with replicated border
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void srt(int &a, int &b) { const int t = min(a, b); b = max(a, b); a = t; }
+
+__global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const int16_t *s = src + (size_t)blockIdx.z * W * H;
+    const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+    int p0 = s[(size_t)ym * W + xm], p1 = s[(size_t)ym * W + x], p2 = s[(size_t)ym * W + xp];
+    int p3 = s[(size_t)y * W + xm], p4 = s[(size_t)y * W + x], p5 = s[(size_t)y * W + xp];
+    int p6 = s[(size_t)yp * W + xm], p7 = s[(size_t)yp * W + x], p8 = s[(size_t)yp * W + xp];
+    srt(p1, p2); srt(p4, p5); srt(p7, p8); srt(p0, p1); srt(p3, p4); srt(p6, p7);
+    srt(p1, p2); srt(p4, p5); srt(p7, p8); srt(p0, p3); srt(p5, p8); srt(p4, p7);
+    srt(p3, p6); srt(p1, p4); srt(p2, p5); srt(p4, p7); srt(p4, p2); srt(p6, p4);
+    srt(p4, p2);
+    dst[(size_t)blockIdx.z * W * H + (size_t)y * W + x] = (int16_t)p4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: speckle filter = connected components (4-neighbourhood, |a-b| <= maxDiff) by lock-free
+// union-find, then size threshold.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_load(const int *L, int i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int uf_find(const int *L, int i)
+{
+    int r = i, p;
+    while ((p = uf_load(L, r)) != r) r = p;
+    return r;
+}
+__device__ __forceinline__ void uf_union(int *L, int a, int b)
+{
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(L + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_speckle_init(const int16_t *__restrict__ disp, size_t n, int newVal, int *__restrict__ labels, int *__restrict__ sizes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    labels[i] = (disp[i] != newVal) ? (int)i : -1;
+    sizes[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_speckle_merge(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int *labels)
+{
+    const size_t n = (size_t)W * H * B;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = disp[i];
+    if (v == newVal) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    if (x + 1 < W) { const int u = disp[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + 1); }
+    if (y + 1 < H) { const int u = disp[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + W); }
+}
+__global__ void __launch_bounds__(256) k_speckle_count(size_t n, int *labels, int *sizes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (labels[i] < 0) return;
+    int r = (int)i, p;
+    while ((p = labels[r]) != r) r = p;
+    labels[i] = r;
+    atomicAdd(sizes + r, 1);
+}
+__global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, size_t n, int newVal, int maxSize, const int *__restrict__ labels, const int *__restrict__ sizes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = labels[i];
+    if (r < 0) return;
+    // k_speckle_count left labels[i] pointing at the root of its component
+    if (sizes[r] <= maxSize) disp[i] = (int16_t)newVal;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
+{
+    std::memset(g, 0, sizeof(*g));
+    g->W = W; g->H = H;
+    g->minD = p->minDisparity;
+    g->D = p->numDisparities;
+    const int maxD = g->minD + g->D;
+    g->SW2 = g->SH2 = p->blockSize > 0 ? p->blockSize / 2 : 1;
+    g->P1 = p->P1 > 0 ? p->P1 : 2;
+    g->P2 = std::max(p->P2 > 0 ? p->P2 : 5, g->P1 + 1);
+    g->uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    g->disp12MaxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
+    g->ftzero = std::max(p->preFilterCap, 15) | 1;
+    g->minX1 = std::max(maxD, 0);
+    g->maxX1 = W + std::min(g->minD, 0);
+    g->W1 = g->maxX1 - g->minX1;
+    g->invalid16 = (g->minD - 1) * 16;
+    g->stripe_sz = (H + 3) / 4;
+    g->stripe_overlap = (g->SH2 + 1) + (int)std::ceil(0.1 * g->stripe_sz);
+    g->speckleWindowSize = p->speckleWindowSize;
+    g->speckleRange = p->speckleRange;
+    g->NP = g->D / 32;
+    return 0;
+}
+
+} // namespace l3d
+
+using namespace l3d;
+
+struct l3d_sgbm {
+    SgbmGeom g;
+    int device = 0, max_batch = 0, last_batch = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *in_left = nullptr, *in_right = nullptr; // staging for the host entry point
+    int16_t *out_disp = nullptr;
+    uint2 *lrec = nullptr;
+    uint8_t *rrev = nullptr;
+    uint32_t *Cvol = nullptr, *Tvol = nullptr, *Lvol = nullptr, *wta = nullptr;
+    int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
+    int *labels = nullptr, *sizes = nullptr;
+    size_t lds_vertical = 0;
+};
+
+extern "C" int l3d_sgbm_geometry(const l3d_sgbm_params *params, int width, int height, int *out8)
+{
+    L3D_REQUIRE(params && out8, "l3d_sgbm_geometry: null argument");
+    SgbmGeom g;
+    sgbm_make_geom(params, width, height, &g);
+    out8[0] = g.minX1; out8[1] = g.W1; out8[2] = g.stripe_sz; out8[3] = g.stripe_overlap;
+    out8[4] = g.invalid16; out8[5] = g.ftzero; out8[6] = g.P1; out8[7] = g.P2;
+    return L3D_OK;
+}
+
+extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
+{
+    if (!h) return;
+    DeviceGuard dg(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Lvol,
+                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, int max_batch, int device, l3d_sgbm **out)
+{
+    L3D_REQUIRE(p && out, "l3d_sgbm_create: null argument");
+    *out = nullptr;
+    L3D_REQUIRE(width >= 3 && height >= 1 && max_batch >= 1, "l3d_sgbm_create: bad size %dx%d batch %d", width, height, max_batch);
+    L3D_REQUIRE(width <= 65535, "l3d_sgbm_create: width %d exceeds 65535", width);
+    if (p->mode != 2) {
+        set_error("l3d_sgbm_create: only mode=2 (STEREO_SGBM_MODE_SGBM_3WAY) is built, got %d", p->mode);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    if (p->numDisparities <= 0 || p->numDisparities % 32 != 0 || p->numDisparities > 256) {
+        set_error("l3d_sgbm_create: numDisparities must be a multiple of 32 in [32, 256], got %d", p->numDisparities);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    if (p->blockSize > 21) {
+        set_error("l3d_sgbm_create: blockSize %d > 21 is not supported", p->blockSize);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("l3d_sgbm_create: no HIP device available");
+        return L3D_ERR_NO_DEVICE;
+    }
+    L3D_REQUIRE(device >= 0 && device < ndev, "l3d_sgbm_create: device %d out of range (%d devices)", device, ndev);
+    l3d_sgbm *h = new (std::nothrow) l3d_sgbm();
+    L3D_REQUIRE(h, "l3d_sgbm_create: out of host memory");
+    sgbm_make_geom(p, width, height, &h->g);
+    h->device = device;
+    h->max_batch = max_batch;
+    const SgbmGeom &g = h->g;
+    if (g.W1 > 0 && g.stripe_overlap > g.stripe_sz) {
+        delete h;
+        set_error("l3d_sgbm_create: height %d too small for blockSize %d (4-stripe scheme needs overlap %d <= stripe %d)",
+                  height, p->blockSize, g.stripe_overlap, g.stripe_sz);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    h->lds_vertical = ((size_t)(16 + 2 * g.SW2) * 16 * g.NP + (size_t)(2 * g.SH2 + 2) * 256 * g.NP) * sizeof(uint32_t);
+    if (h->lds_vertical > 160 * 1024) {
+        delete h;
+        set_error("l3d_sgbm_create: blockSize %d with numDisparities %d needs %zu B of LDS (> 160 KiB)", p->blockSize, g.D, h->lds_vertical);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    DeviceGuard dg(device);
+    const size_t B = (size_t)max_batch, px = (size_t)width * height;
+    const size_t vol = g.W1 > 0 ? B * height * (size_t)g.W1 * g.D * sizeof(int16_t) : 0;
+    const size_t cols = g.W1 > 0 ? B * height * (size_t)g.W1 : 0;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    auto alloc = [&](void **ptr, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void **)&h->in_left, B * px);
+    alloc((void **)&h->in_right, B * px);
+    alloc((void **)&h->out_disp, B * px * 2);
+    alloc((void **)&h->lrec, B * px * sizeof(uint2));
+    alloc((void **)&h->rrev, B * px * 6 + 64);
+    alloc((void **)&h->Cvol, vol);
+    alloc((void **)&h->Tvol, vol);
+    alloc((void **)&h->Lvol, vol);
+    alloc((void **)&h->wta, cols * 4);
+    alloc((void **)&h->dsub, cols * 2);
+    alloc((void **)&h->raw, B * px * 2);
+    alloc((void **)&h->med, B * px * 2);
+    if (p->speckleWindowSize > 0) {
+        alloc((void **)&h->labels, B * px * 4);
+        alloc((void **)&h->sizes, B * px * 4);
+    }
+    if (e != hipSuccess) {
+        set_error("l3d_sgbm_create: allocation failed: %s", hipGetErrorString(e));
+        l3d_sgbm_destroy(h);
+        return L3D_ERR_HIP;
+    }
+    if (h->lds_vertical > 64 * 1024) {
+        // opt in to more than 64 KiB of dynamic LDS per block
+        const void *fns[] = {(const void *)k_cost_vertical<1>, (const void *)k_cost_vertical<2>, (const void *)k_cost_vertical<3>,
+                             (const void *)k_cost_vertical<4>, (const void *)k_cost_vertical<5>, (const void *)k_cost_vertical<6>,
+                             (const void *)k_cost_vertical<7>, (const void *)k_cost_vertical<8>};
+        e = hipFuncSetAttribute(fns[g.NP - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_vertical);
+        if (e != hipSuccess) {
+            set_error("l3d_sgbm_create: cannot reserve %zu B of LDS: %s", h->lds_vertical, hipGetErrorString(e));
+            l3d_sgbm_destroy(h);
+            return L3D_ERR_HIP;
+        }
+    }
+    *out = h;
+    return L3D_OK;
+}
+
+template <int NP>
+static void launch_core(l3d_sgbm *h, int B, hipStream_t s)
+{
+    const SgbmGeom &g = h->g;
+    dim3 gv(cdiv(g.W1, 16), 4, B);
+    hipLaunchKernelGGL(k_cost_vertical<NP>, gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
+    const int nrows = B * g.H;
+    hipLaunchKernelGGL(k_horizontal<NP>, dim3(cdiv(nrows, 4)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
+}
+
+static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
+{
+    const SgbmGeom &g = h->g;
+    const size_t px = (size_t)g.W * g.H;
+    const size_t n = px * B;
+    h->last_batch = B;
+    if (g.W1 <= 0) {
+        // no column has a full disparity range: the whole map is invalid
+        // (median of a constant image and the speckle filter leave it unchanged)
+        std::vector<int16_t> fill(n, (int16_t)g.invalid16);
+        L3D_HIP_CHECK(hipMemcpyAsync(d_disp, fill.data(), n * 2, hipMemcpyHostToDevice, s));
+        L3D_HIP_CHECK(hipStreamSynchronize(s));
+        return L3D_OK;
+    }
+    hipLaunchKernelGGL(k_prefilter, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
+    switch (g.NP) {
+    case 1: launch_core<1>(h, B, s); break;
+    case 2: launch_core<2>(h, B, s); break;
+    case 3: launch_core<3>(h, B, s); break;
+    case 4: launch_core<4>(h, B, s); break;
+    case 5: launch_core<5>(h, B, s); break;
+    case 6: launch_core<6>(h, B, s); break;
+    case 7: launch_core<7>(h, B, s); break;
+    case 8: launch_core<8>(h, B, s); break;
+    default: set_error("sgbm: unsupported NP %d", g.NP); return L3D_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(256), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
+    const bool speckle = g.speckleWindowSize > 0;
+    hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
+    if (speckle) {
+        const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_speckle_init, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, h->labels, h->sizes);
+        hipLaunchKernelGGL(k_speckle_merge, dim3(nb), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, h->labels);
+        hipLaunchKernelGGL(k_speckle_count, dim3(nb), dim3(256), 0, s, n, h->labels, h->sizes);
+        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, g.speckleWindowSize, h->labels, h->sizes);
+    }
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch, int16_t *d_disp, void *stream)
+{
+    L3D_REQUIRE(h && d_left && d_right && d_disp, "l3d_sgbm_compute_device: null argument");
+    L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_sgbm_compute_device: batch %d outside [1, %d]", batch, h->max_batch);
+    DeviceGuard dg(h->device);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    return sgbm_run(h, d_left, d_right, batch, d_disp, s);
+}
+
+extern "C" int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int batch, ptrdiff_t row_stride,
+                                ptrdiff_t img_stride, int16_t *disp)
+{
+    L3D_REQUIRE(h && left && right && disp, "l3d_sgbm_compute: null argument");
+    L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_sgbm_compute: batch %d outside [1, %d]", batch, h->max_batch);
+    const SgbmGeom &g = h->g;
+    L3D_REQUIRE(row_stride >= g.W, "l3d_sgbm_compute: row_stride %td < width %d", row_stride, g.W);
+    DeviceGuard dg(h->device);
+    hipStream_t s = h->stream;
+    const size_t px = (size_t)g.W * g.H;
+    for (int b = 0; b < batch; b++) {
+        L3D_HIP_CHECK(hipMemcpy2DAsync(h->in_left + b * px, g.W, left + b * img_stride, row_stride, g.W, g.H, hipMemcpyHostToDevice, s));
+        L3D_HIP_CHECK(hipMemcpy2DAsync(h->in_right + b * px, g.W, right + b * img_stride, row_stride, g.W, g.H, hipMemcpyHostToDevice, s));
+    }
+    int rc = sgbm_run(h, h->in_left, h->in_right, batch, h->out_disp, s);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipMemcpyAsync(disp, h->out_disp, px * batch * 2, hipMemcpyDeviceToHost, s));
+    L3D_HIP_CHECK(hipStreamSynchronize(s));
+    return L3D_OK;
+}
+
+extern "C" int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size_t bytes)
+{
+    L3D_REQUIRE(h && host_dst, "l3d_sgbm_fetch_stage: null argument");
+    const SgbmGeom &g = h->g;
+    const size_t B = (size_t)h->last_batch;
+    const size_t vol = g.W1 > 0 ? B * g.H * (size_t)g.W1 * g.D * 2 : 0;
+    const size_t img = B * g.W * g.H * 2;
+    const void *src = nullptr;
+    size_t avail = 0;
+    switch (stage) {
+    case 0: src = h->Cvol; avail = vol; break;
+    case 1: src = h->Tvol; avail = vol; break;
+    case 2: src = h->raw; avail = img; break;
+    default: set_error("l3d_sgbm_fetch_stage: unknown stage %d", stage); return L3D_ERR_INVALID_ARG;
+    }
+    L3D_REQUIRE(bytes <= avail, "l3d_sgbm_fetch_stage: %zu bytes requested, stage holds %zu", bytes, avail);
+    DeviceGuard dg(h->device);
+    L3D_HIP_CHECK(hipStreamSynchronize(h->stream));
+    L3D_HIP_CHECK(hipDeviceSynchronize());
+    L3D_HIP_CHECK(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
