@@ -1,0 +1,204 @@
+"""SingleUSBStereoCameraManager with the reference's constructor, attributes and
+methods (camera/single_usb_stereo_camera.py:13-389), computing depth on the GPU.
+
+Differences a caller can see:
+  * ``compute_depth(left_img, right_img)`` is the frame-pair entry point the
+    reference's README sketches (readme.md:367); ``get_frames`` delegates to it.
+  * frames come from ``frame_source`` (any object with ``read() -> (ok, frame)``,
+    ``isOpened()`` and ``release()``) instead of a cv2.VideoCapture, because
+    camera capture is outside the accelerated path.
+  * when a ``Config`` is given, its STEREO_* knobs select the matcher parameters
+    (the reference prints them but always uses its width rule); without one the
+    reference's width rule applies (:239-248).
+  * the rectification maps are not generated here yet (remap is the step before
+    this path); Q may be supplied directly, or is taken from the calibration
+    file's own "Q" entry.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .. import ops, stereo
+
+
+class SingleUSBStereoCameraManager:
+    def __init__(self, camera_id: int = 0, width: int = 640, height: int = 240, fps: int = 30,
+                 split_mode: str = 'horizontal', calibration_file: str = 'stereo_calibration.json',
+                 config=None, device: int = 0, frame_source=None, verbose: bool = False, max_batch: int = 1):
+        self.camera_id = camera_id
+        self.width = width
+        self.height = height
+        self.fps = fps
+        self.split_mode = split_mode
+        self.calibration_file = calibration_file
+        self.config = config
+        self.device = device
+        self.verbose = verbose
+        self.max_batch = max_batch
+
+        self.cap = frame_source
+        self.camera_matrix_left = None
+        self.dist_coeffs_left = None
+        self.camera_matrix_right = None
+        self.dist_coeffs_right = None
+        self.R = None
+        self.T = None
+        self.R1 = self.R2 = self.P1 = self.P2 = self.Q = None
+        self.roi_left = self.roi_right = None
+        self.map_left_x = self.map_left_y = self.map_right_x = self.map_right_y = None
+        self.stereo_matcher = None
+        self.right_matcher = None
+        self.wls_filter = None
+        self.use_wls = True
+
+        if split_mode == 'horizontal':
+            self.single_width = width // 2
+            self.single_height = height
+        else:
+            self.single_width = width
+            self.single_height = height // 2
+        self._log(f"stereo camera manager: total {width}x{height}, per eye {self.single_width}x{self.single_height}, {split_mode}")
+
+    def _log(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # ------------------------------------------------------------------ init
+    def initialize(self) -> bool:
+        if self.cap is None or not self.cap.isOpened():
+            self._log(f"cannot open camera {self.camera_id}: no frame source")
+            return False
+        ret, frame = self.cap.read()
+        if not ret or frame is None:
+            self._log("cannot read a frame")
+            return False
+        if not self._load_calibration():
+            self._use_default_calibration()
+        self._initialize_stereo_matcher_optimized()
+        for _ in range(10):
+            self.cap.read()
+        return True
+
+    def initialize_offline(self) -> bool:
+        """Calibration + matcher set-up without a frame source (for compute_depth on caller-supplied pairs)."""
+        if not self._load_calibration():
+            self._use_default_calibration()
+        self._initialize_stereo_matcher_optimized()
+        return True
+
+    def _split_frame(self, frame: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        if self.split_mode == 'horizontal':
+            mid = frame.shape[1] // 2
+            return frame[:, :mid], frame[:, mid:]
+        mid = frame.shape[0] // 2
+        return frame[:mid, :], frame[mid:, :]
+
+    def _load_calibration(self) -> bool:
+        if not self.calibration_file or not os.path.exists(self.calibration_file):
+            self._log(f"calibration file not found: {self.calibration_file}")
+            return False
+        try:
+            with open(self.calibration_file, 'r', encoding='utf-8') as f:
+                calib = json.load(f)
+            self.camera_matrix_left = np.array(calib['camera_matrix_left'])
+            self.dist_coeffs_left = np.array(calib['dist_coeffs_left'])
+            self.camera_matrix_right = np.array(calib['camera_matrix_right'])
+            self.dist_coeffs_right = np.array(calib['dist_coeffs_right'])
+            self.R = np.array(calib['R'])
+            self.T = np.array(calib['T'])
+            for key in ('R1', 'R2', 'P1', 'P2', 'Q'):
+                if key in calib:
+                    setattr(self, key, np.array(calib[key], dtype=np.float64))
+            return True
+        except Exception as e:  # same convention as the reference: report and fall back
+            self._log(f"calibration load failed: {e}")
+            return False
+
+    def _use_default_calibration(self):
+        fx = fy = 350.0
+        cx = self.single_width / 2.0
+        cy = self.single_height / 2.0
+        self.camera_matrix_left = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+        self.camera_matrix_right = self.camera_matrix_left.copy()
+        self.dist_coeffs_left = np.zeros((1, 5))
+        self.dist_coeffs_right = np.zeros((1, 5))
+
+    def _matcher_knobs(self):
+        cfg = self.config
+        if cfg is not None:
+            return (int(cfg.STEREO_NUM_DISPARITIES), int(cfg.STEREO_BLOCK_SIZE), bool(cfg.STEREO_USE_WLS_FILTER),
+                    float(cfg.STEREO_LAMBDA), float(cfg.STEREO_SIGMA))
+        if self.single_width < 400:
+            return 64, 5, True, 8000.0, 1.5
+        return 96, 7, True, 8000.0, 1.5
+
+    def _initialize_stereo_matcher_optimized(self):
+        num_disparities, block_size, use_wls, lam, sigma = self._matcher_knobs()
+        self.use_wls = use_wls
+        self.stereo_matcher = stereo.StereoSGBM_create(
+            minDisparity=0, numDisparities=num_disparities, blockSize=block_size,
+            P1=8 * 3 * block_size ** 2, P2=32 * 3 * block_size ** 2,
+            disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100, speckleRange=32,
+            preFilterCap=63, mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY,
+            device=self.device, max_batch=self.max_batch)
+        if use_wls:
+            self.right_matcher = stereo.createRightMatcher(self.stereo_matcher)
+            self.wls_filter = stereo.createDisparityWLSFilter(self.stereo_matcher)
+            self.wls_filter.setLambda(lam)
+            self.wls_filter.setSigmaColor(sigma)
+        self._log(f"SGBM_3WAY D={num_disparities} block={block_size} wls={use_wls}")
+
+    # ------------------------------------------------------------- per frame
+    def _to_gray(self, img: np.ndarray) -> np.ndarray:
+        if img.ndim == 3 and img.shape[-1] == 3:
+            return ops.bgr2gray(img, device=self.device)
+        return np.ascontiguousarray(img)
+
+    def compute_disparity(self, left_img: np.ndarray, right_img: np.ndarray) -> np.ndarray:
+        """int16 disparity*16 of a rectified pair: SGBM (+ right SGBM + WLS when enabled)."""
+        if self.stereo_matcher is None:
+            self._initialize_stereo_matcher_optimized()
+        left_gray = self._to_gray(left_img)
+        right_gray = self._to_gray(right_img)
+        disparity_left = self.stereo_matcher.compute(left_gray, right_gray)
+        if self.use_wls and self.wls_filter is not None:
+            disparity_right = self.right_matcher.compute(right_gray, left_gray)
+            return self.wls_filter.filter(disparity_left, left_gray, disparity_map_right=disparity_right)
+        return disparity_left
+
+    def compute_depth(self, left_img: np.ndarray, right_img: np.ndarray) -> np.ndarray:
+        """Depth map (float32, Q units, 0 = invalid) of a rectified BGR or gray pair; the body of
+        the reference's get_frames from the gray conversion on (:319-357)."""
+        disp16 = self.compute_disparity(left_img, right_img)
+        return ops.depth_from_disparity16(disp16, self.Q, device=self.device)
+
+    def get_frames(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        if self.cap is None or not self.cap.isOpened():
+            return None, None
+        ret, frame = self.cap.read()
+        if not ret:
+            return None, None
+        left_img, right_img = self._split_frame(frame)
+        left_rectified = np.ascontiguousarray(left_img)
+        right_rectified = np.ascontiguousarray(right_img)
+        depth_map = self.compute_depth(left_rectified, right_rectified)
+        return left_rectified, depth_map
+
+    def get_camera_intrinsics(self) -> Optional[Dict]:
+        if self.camera_matrix_left is None:
+            return None
+        K = self.P1[:3, :3] if self.P1 is not None else self.camera_matrix_left
+        baseline = np.linalg.norm(self.T) if self.T is not None else 0.06
+        return {
+            'width': self.single_width, 'height': self.single_height,
+            'fx': float(K[0, 0]), 'fy': float(K[1, 1]), 'cx': float(K[0, 2]), 'cy': float(K[1, 2]),
+            'baseline': float(baseline),
+        }
+
+    def stop(self):
+        if self.cap is not None:
+            self.cap.release()

@@ -1,0 +1,306 @@
+// Colour conversion, disparity -> depth, and laser-pixel -> 3-D kernels for gfx950.
+//
+// Replaces cv2.cvtColor(BGR2GRAY), `.astype(float32)/16`, cv2.reprojectImageTo3D and the
+// validity masks of the reference (camera/single_usb_stereo_camera.py:320-321, 335-357) and
+// Reconstructor.reconstruct_from_depth / reconstruct_point (core/reconstruction.py:30-182).
+// All of these are element-wise, HBM-bound kernels (the gray conversion handles 4 adjacent
+// pixels per thread so that its loads and stores are whole dwords).
+#include "common.h"
+#include <cmath>
+#include <vector>
+
+namespace l3d {
+
+// 8-bit BGR -> gray in 15-bit fixed point: Y = (R*9798 + G*19235 + B*3735 + 2^14) >> 15
+__device__ __forceinline__ uint32_t gray_px(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (r * 9798u + g * 19235u + b * 3735u + (1u << 14)) >> 15;
+}
+
+__global__ void __launch_bounds__(256) k_bgr2gray(const uint8_t *__restrict__ bgr, size_t npx, uint8_t *__restrict__ gray)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // group of 4 pixels
+    const size_t p0 = q * 4;
+    if (p0 >= npx) return;
+    if (p0 + 4 <= npx) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(bgr + p0 * 3); // 12-byte aligned to 4
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+        const uint32_t y0 = gray_px(w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff);
+        const uint32_t y1 = gray_px(w0 >> 24, w1 & 0xff, (w1 >> 8) & 0xff);
+        const uint32_t y2 = gray_px((w1 >> 16) & 0xff, w1 >> 24, w2 & 0xff);
+        const uint32_t y3 = gray_px((w2 >> 8) & 0xff, (w2 >> 16) & 0xff, w2 >> 24);
+        *reinterpret_cast<uint32_t *>(gray + p0) = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+    } else {
+        for (size_t p = p0; p < npx; p++) gray[p] = (uint8_t)gray_px(bgr[3 * p], bgr[3 * p + 1], bgr[3 * p + 2]);
+    }
+}
+
+struct QMat {
+    double q[16];
+};
+
+// Z of cv2.reprojectImageTo3D for float disparity d at (x, y): the homogeneous point is
+// computed in double, cast to float, then divided by the double W.
+__global__ void __launch_bounds__(256) k_depth(const int16_t *__restrict__ disp16, int W, int H, int B, QMat Q, int calibrated,
+                                               float *__restrict__ depth, float *__restrict__ xyz)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const size_t i = ((size_t)b * H + y) * W + x;
+    const float d = (float)disp16[i] / 16.0f;
+    float z;
+    if (calibrated) {
+        const double dd = (double)d, xd = (double)x, yd = (double)y;
+        double hp[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double s = 0.0;
+            s += Q.q[4 * r + 0] * xd;
+            s += Q.q[4 * r + 1] * yd;
+            s += Q.q[4 * r + 2] * dd;
+            s += Q.q[4 * r + 3] * 1.0;
+            hp[r] = s;
+        }
+        const float X = (float)((double)(float)hp[0] / hp[3]);
+        const float Y = (float)((double)(float)hp[1] / hp[3]);
+        const float Z = (float)((double)(float)hp[2] / hp[3]);
+        if (xyz) { xyz[3 * i] = X; xyz[3 * i + 1] = Y; xyz[3 * i + 2] = Z; }
+        z = Z;
+        if (z < 0.0f) z = 0.0f;
+        if (z > 10.0f) z = 0.0f;
+        if (d <= 0.0f) z = 0.0f;
+    } else {
+        z = 0.0f;
+        if (d > 0.0f) z = (float)((0.06 * 350) / (double)d);
+        if (z > 10.0f) z = 0.0f;
+    }
+    depth[i] = z;
+}
+
+// reconstruct_from_depth for n laser pixels: keep[i] = 1 and xyz[i] valid where the reference
+// appends a point.  Compaction (order preserving) happens on the host: n is a few thousand.
+__global__ void __launch_bounds__(256) k_from_depth(const double *__restrict__ uv, int n, const float *__restrict__ depth, int W, int H,
+                                                    double fx, double fy, double cx, double cy, double *__restrict__ xyz, int *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = uv[2 * i], v = uv[2 * i + 1];
+    int k = 0;
+    if (u == u && v == v && fabs(u) < 2147483000.0 && fabs(v) < 2147483000.0) {
+        const long iu = (long)u, iv = (long)v; // truncation toward zero, as Python int()
+        if (0 <= iu && iu < W && 0 <= iv && iv < H) {
+            const float dep = depth[(size_t)iv * W + iu];
+            if (dep > 0) {
+                const double z = (double)dep / 1000.0;
+                xyz[3 * i] = (u - cx) * z / fx;
+                xyz[3 * i + 1] = (v - cy) * z / fy;
+                xyz[3 * i + 2] = z;
+                k = 1;
+            }
+        }
+    }
+    keep[i] = k;
+}
+
+struct PlaneArgs {
+    double kinv[9];
+    double plane[4];
+    double n_water;
+    int refraction;
+};
+
+__global__ void __launch_bounds__(256) k_plane(const double *__restrict__ uv, int n, PlaneArgs a, double *__restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = uv[2 * i], v = uv[2 * i + 1];
+    double r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = a.kinv[3 * k] * u + a.kinv[3 * k + 1] * v + a.kinv[3 * k + 2] * 1.0;
+    const double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] /= nr; r[1] /= nr; r[2] /= nr;
+    const double pa = a.plane[0], pb = a.plane[1], pc = a.plane[2], pd = a.plane[3];
+    const double den = pa * r[0] + pb * r[1] + pc * r[2];
+    double *o = xyz + 3 * (size_t)i;
+    const double qnan = __builtin_nan("");
+    if (fabs(den) < 1e-10) { o[0] = o[1] = o[2] = qnan; return; }
+    const double t = -pd / den;
+    if (t < 0) { o[0] = o[1] = o[2] = qnan; return; }
+    double P[3] = {t * r[0], t * r[1], t * r[2]};
+    if (a.refraction) {
+        const double n1 = 1.0, n2 = a.n_water;
+        const double cos1 = -(r[2]);
+        const double sin1 = sqrt(1 - cos1 * cos1);
+        const double sin2 = (n1 / n2) * sin1;
+        if (!(sin2 > 1)) {
+            const double cos2 = sqrt(1 - sin2 * sin2);
+            double q[3] = {(n1 / n2) * r[0], (n1 / n2) * r[1], (n1 / n2) * r[2] + ((n1 / n2) * cos1 - cos2)};
+            const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            q[0] /= nq; q[1] /= nq; q[2] /= nq;
+            const double den2 = pa * q[0] + pb * q[1] + pc * q[2];
+            if (!(fabs(den2) < 1e-10)) {
+                const double t2 = -pd / den2;
+                P[0] = t2 * q[0]; P[1] = t2 * q[1]; P[2] = t2 * q[2];
+            }
+        }
+    }
+    o[0] = P[0]; o[1] = P[1]; o[2] = P[2];
+}
+
+static int check_device(int device, const char *who)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("%s: no HIP device available", who);
+        return L3D_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("%s: device %d out of range (%d devices)", who, device, ndev);
+        return L3D_ERR_INVALID_ARG;
+    }
+    return L3D_OK;
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+} // namespace l3d
+
+using namespace l3d;
+
+extern "C" int l3d_bgr2gray_device(const uint8_t *d_bgr, int width, int height, int batch, uint8_t *d_gray, int device, void *stream)
+{
+    L3D_REQUIRE(d_bgr && d_gray, "l3d_bgr2gray_device: null argument");
+    L3D_REQUIRE(width > 0 && height > 0 && batch > 0, "l3d_bgr2gray_device: bad size");
+    L3D_REQUIRE(((uintptr_t)d_bgr & 3) == 0 && ((uintptr_t)d_gray & 3) == 0, "l3d_bgr2gray_device: pointers must be 4-byte aligned");
+    int rc = check_device(device, "l3d_bgr2gray_device");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    const size_t npx = (size_t)width * height * batch;
+    const size_t groups = (npx + 3) / 4;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_bgr, npx, d_gray);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_bgr2gray(const uint8_t *bgr, int width, int height, int batch, uint8_t *gray, int device)
+{
+    L3D_REQUIRE(bgr && gray, "l3d_bgr2gray: null argument");
+    L3D_REQUIRE(width > 0 && height > 0 && batch > 0, "l3d_bgr2gray: bad size");
+    int rc = check_device(device, "l3d_bgr2gray");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    const size_t npx = (size_t)width * height * batch;
+    DevBuf in, out;
+    L3D_HIP_CHECK(in.alloc(npx * 3));
+    L3D_HIP_CHECK(out.alloc(npx));
+    L3D_HIP_CHECK(hipMemcpy(in.p, bgr, npx * 3, hipMemcpyHostToDevice));
+    rc = l3d_bgr2gray_device((const uint8_t *)in.p, width, height, batch, (uint8_t *)out.p, device, nullptr);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipDeviceSynchronize());
+    L3D_HIP_CHECK(hipMemcpy(gray, out.p, npx, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
+
+extern "C" int l3d_depth_from_disp16_device(const int16_t *d_disp16, const double *Q16_host, int width, int height, int batch,
+                                            float *d_depth, float *d_xyz, int device, void *stream)
+{
+    L3D_REQUIRE(d_disp16 && d_depth, "l3d_depth_from_disp16_device: null argument");
+    L3D_REQUIRE(width > 0 && height > 0 && batch > 0, "l3d_depth_from_disp16_device: bad size");
+    L3D_REQUIRE(!(d_xyz && !Q16_host), "l3d_depth_from_disp16_device: xyz output needs Q");
+    int rc = check_device(device, "l3d_depth_from_disp16_device");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    QMat Q;
+    for (int i = 0; i < 16; i++) Q.q[i] = Q16_host ? Q16_host[i] : 0.0;
+    hipLaunchKernelGGL(k_depth, dim3(cdiv(width, 256), height, batch), dim3(256), 0, (hipStream_t)stream, d_disp16, width, height, batch, Q,
+                       Q16_host ? 1 : 0, d_depth, d_xyz);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_depth_from_disp16(const int16_t *disp16, const double *Q16, int width, int height, int batch, float *depth,
+                                     float *xyz, int device)
+{
+    L3D_REQUIRE(disp16 && depth, "l3d_depth_from_disp16: null argument");
+    L3D_REQUIRE(width > 0 && height > 0 && batch > 0, "l3d_depth_from_disp16: bad size");
+    int rc = check_device(device, "l3d_depth_from_disp16");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    const size_t npx = (size_t)width * height * batch;
+    DevBuf in, out, out3;
+    L3D_HIP_CHECK(in.alloc(npx * 2));
+    L3D_HIP_CHECK(out.alloc(npx * 4));
+    if (xyz) L3D_HIP_CHECK(out3.alloc(npx * 12));
+    L3D_HIP_CHECK(hipMemcpy(in.p, disp16, npx * 2, hipMemcpyHostToDevice));
+    rc = l3d_depth_from_disp16_device((const int16_t *)in.p, Q16, width, height, batch, (float *)out.p, xyz ? (float *)out3.p : nullptr, device, nullptr);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipDeviceSynchronize());
+    L3D_HIP_CHECK(hipMemcpy(depth, out.p, npx * 4, hipMemcpyDeviceToHost));
+    if (xyz) L3D_HIP_CHECK(hipMemcpy(xyz, out3.p, npx * 12, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
+
+extern "C" int l3d_reconstruct_from_depth(const double *uv, int n, const float *depth, int width, int height, const double *K9,
+                                          double *xyz, int *n_out, int device)
+{
+    L3D_REQUIRE(n_out, "l3d_reconstruct_from_depth: null argument");
+    *n_out = 0;
+    L3D_REQUIRE(n >= 0 && width > 0 && height > 0, "l3d_reconstruct_from_depth: bad size");
+    if (n == 0) return L3D_OK;
+    L3D_REQUIRE(uv && depth && K9 && xyz, "l3d_reconstruct_from_depth: null argument");
+    int rc = check_device(device, "l3d_reconstruct_from_depth");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    DevBuf duv, ddep, dxyz, dkeep;
+    L3D_HIP_CHECK(duv.alloc((size_t)n * 16));
+    L3D_HIP_CHECK(ddep.alloc((size_t)width * height * 4));
+    L3D_HIP_CHECK(dxyz.alloc((size_t)n * 24));
+    L3D_HIP_CHECK(dkeep.alloc((size_t)n * 4));
+    L3D_HIP_CHECK(hipMemcpy(duv.p, uv, (size_t)n * 16, hipMemcpyHostToDevice));
+    L3D_HIP_CHECK(hipMemcpy(ddep.p, depth, (size_t)width * height * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_from_depth, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, (const float *)ddep.p, width, height,
+                       K9[0], K9[4], K9[2], K9[5], (double *)dxyz.p, (int *)dkeep.p);
+    L3D_HIP_CHECK(hipGetLastError());
+    std::vector<double> tmp((size_t)n * 3);
+    std::vector<int> keep(n);
+    L3D_HIP_CHECK(hipMemcpy(tmp.data(), dxyz.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    L3D_HIP_CHECK(hipMemcpy(keep.data(), dkeep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int m = 0;
+    for (int i = 0; i < n; i++)
+        if (keep[i]) {
+            xyz[3 * m] = tmp[3 * i]; xyz[3 * m + 1] = tmp[3 * i + 1]; xyz[3 * m + 2] = tmp[3 * i + 2];
+            m++;
+        }
+    *n_out = m;
+    return L3D_OK;
+}
+
+extern "C" int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv9, const double *plane4, int refraction, double n_water,
+                                     double *xyz, int device)
+{
+    L3D_REQUIRE(n >= 0, "l3d_reconstruct_plane: bad size");
+    if (n == 0) return L3D_OK;
+    L3D_REQUIRE(uv && Kinv9 && plane4 && xyz, "l3d_reconstruct_plane: null argument");
+    int rc = check_device(device, "l3d_reconstruct_plane");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    DevBuf duv, dxyz;
+    L3D_HIP_CHECK(duv.alloc((size_t)n * 16));
+    L3D_HIP_CHECK(dxyz.alloc((size_t)n * 24));
+    L3D_HIP_CHECK(hipMemcpy(duv.p, uv, (size_t)n * 16, hipMemcpyHostToDevice));
+    PlaneArgs a;
+    for (int i = 0; i < 9; i++) a.kinv[i] = Kinv9[i];
+    for (int i = 0; i < 4; i++) a.plane[i] = plane4[i];
+    a.n_water = n_water;
+    a.refraction = refraction;
+    hipLaunchKernelGGL(k_plane, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, a, (double *)dxyz.p);
+    L3D_HIP_CHECK(hipGetLastError());
+    L3D_HIP_CHECK(hipMemcpy(xyz, dxyz.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}

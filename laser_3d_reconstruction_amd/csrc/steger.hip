@@ -1,0 +1,384 @@
+// Steger ridge-centre extraction for gfx950.
+//
+// Replaces FastStegerExtractor.extract_centerline / extract_batch of the reference
+// (core/laser_extractor.py:160-261, 279-285): BGR->gray, float GaussianBlur(sigma), five
+// filter2D difference stencils, and the per-pixel Python loop that calls np.linalg.eig on the
+// 2x2 Hessian of every pixel brighter than the threshold.
+//
+// One fused kernel per 64x16 pixel tile:
+//   gray (u8) of the tile -> early exit when no pixel is above the threshold (the laser covers a
+//   few percent of a frame, so most tiles only cost their 3 B/pixel read) -> gray tile with
+//   halo staged in LDS as float -> separable Gaussian through LDS -> stencils, closed-form 2x2
+//   symmetric eigen-decomposition in double, acceptance test -> per-row ballot compaction into
+//   fixed per-(row, tile) cells.
+// A second kernel turns the cell counts into raster-order offsets (one block per image) and
+// copies the points into the dense output, so the result has the order of the reference's
+// `for j: for i:` loop.
+#include "common.h"
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace l3d {
+
+constexpr int TW = 64, TH = 16;
+constexpr int MAX_TAPS = 65;
+
+struct StegerArgs {
+    int W, H;             // full image size
+    int channels;         // 1 or 3
+    int x0, y0, rw, rh;   // region processed (ROI or whole image)
+    int R;                // kernel radius (ksize = 2R+1)
+    int thr;
+    int ntx, nty;         // tiles per region
+};
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ int gray_at(const uint8_t *img, const StegerArgs &a, int x, int y)
+{
+    // (x, y) relative to the region
+    const uint8_t *p = img + ((size_t)(y + a.y0) * a.W + (x + a.x0)) * a.channels;
+    if (a.channels == 3) return (int)(((uint32_t)p[2] * 9798u + (uint32_t)p[1] * 19235u + (uint32_t)p[0] * 3735u + (1u << 14)) >> 15);
+    return p[0];
+}
+
+// Steger decision from the five derivative values (all float, as the reference's arrays);
+// the 2x2 symmetric eigenproblem and the offset are evaluated in double.
+__device__ __forceinline__ bool steger_point(float dx, float dy, float dxx, float dyy, float dxy, double &ox, double &oy)
+{
+    const double a = dxx, b = dxy, c = dyy;
+    double nx, ny;
+    if (b == 0.0) {
+        if (fabs(a) >= fabs(c)) { nx = 1.0; ny = 0.0; }
+        else { nx = 0.0; ny = 1.0; }
+    } else {
+        const double m = 0.5 * (a + c);
+        const double hd = 0.5 * (a - c);
+        const double rr = sqrt(hd * hd + b * b);
+        const double lam = (m >= 0.0) ? m + rr : m - rr;
+        const double v1x = b, v1y = lam - a;
+        const double v2x = lam - c, v2y = b;
+        const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y;
+        if (n1 >= n2) { const double s = 1.0 / sqrt(n1); nx = v1x * s; ny = v1y * s; }
+        else { const double s = 1.0 / sqrt(n2); nx = v2x * s; ny = v2y * s; }
+    }
+    const double den = nx * nx * a + 2.0 * nx * ny * b + ny * ny * c;
+    if (!(fabs(den) > 1e-10)) return false;
+    const double t = -(nx * (double)dx + ny * (double)dy) / den;
+    const double tx = t * nx, ty = t * ny;
+    if (fabs(tx) <= 0.5 && fabs(ty) <= 0.5) { ox = tx; oy = ty; return true; }
+    return false;
+}
+
+// grid: (ntx, nty, batch); block 256 = 4 waves; wave w handles tile rows w, w+4, w+8, w+12
+__global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t *__restrict__ img, const float *__restrict__ taps,
+                                                     float2 *__restrict__ cells, int *__restrict__ cell_counts)
+{
+    extern __shared__ float sm[];
+    const int R = a.R, ks = 2 * R + 1;
+    const int GW = TW + 2 + 2 * R, GH = TH + 2 + 2 * R; // gray tile incl. halo
+    const int BW = TW + 2, BH = TH + 2;                 // blurred tile (+-1 for the stencils)
+    float *gt = sm;                 // [GH][GW]
+    float *hrow = gt + GH * GW;     // [GH][BW]
+    float *bl = hrow + GH * BW;     // [BH][BW]
+    float *tp = bl + BH * BW;       // [ks]
+    volatile int &any_bright = *reinterpret_cast<volatile int *>(tp + ks);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
+    const uint8_t *im = img + (size_t)b * a.W * a.H * a.channels;
+    const size_t cell_base = ((size_t)b * a.rh) * a.ntx;
+
+    if (tid == 0) any_bright = 0;
+    __syncthreads();
+    // own pixels: brightness test on the unblurred gray value
+    int own[4];
+    bool bright = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = tx0 + lane, y = ty0 + wv + 4 * k;
+        own[k] = (x < a.rw && y < a.rh) ? gray_at(im, a, x, y) : -1;
+        bright |= own[k] > a.thr;
+    }
+    if (__ballot(bright) != 0ull && lane == 0) any_bright = 1;
+    __syncthreads();
+    if (!any_bright) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int y = ty0 + wv + 4 * k;
+                if (y < a.rh) cell_counts[cell_base + (size_t)y * a.ntx + blockIdx.x] = 0;
+            }
+        }
+        return;
+    }
+
+    for (int i = tid; i < ks; i += 256) tp[i] = taps[i];
+    // gray tile with halo; coordinates outside the region are mirrored (BORDER_REFLECT_101)
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int gy = i / GW, gx = i - gy * GW;
+        const int x = reflect101(tx0 - 1 - R + gx, a.rw), y = reflect101(ty0 - 1 - R + gy, a.rh);
+        gt[i] = (float)gray_at(im, a, x, y);
+    }
+    __syncthreads();
+    // row pass: taps accumulated left to right
+    for (int i = tid; i < GH * BW; i += 256) {
+        const int gy = i / BW, bx = i - gy * BW;
+        const float *src = gt + gy * GW + bx;
+        float s = 0.0f;
+        for (int k = 0; k < ks; k++) s = s + tp[k] * src[k];
+        hrow[i] = s;
+    }
+    __syncthreads();
+    // column pass: centre tap, then symmetric pairs
+    for (int i = tid; i < BH * BW; i += 256) {
+        const int by = i / BW, bx = i - by * BW;
+        const float *src = hrow + (by + R) * BW + bx;
+        float s = tp[R] * src[0];
+        for (int k = 1; k <= R; k++) s = s + tp[R + k] * (src[-k * BW] + src[k * BW]);
+        bl[i] = s;
+    }
+    __syncthreads();
+
+    // blurred value at region coordinates (x, y), mirrored at the region border
+    auto B = [&](int x, int y) -> float {
+        const int xr = reflect101(x, a.rw), yr = reflect101(y, a.rh);
+        return bl[(yr - ty0 + 1) * BW + (xr - tx0 + 1)];
+    };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = tx0 + lane, y = ty0 + wv + 4 * k;
+        if (y >= a.rh) continue; // wave-uniform
+        bool acc = false;
+        double ox = 0.0, oy = 0.0;
+        if (own[k] > a.thr) {
+            const float c = B(x, y), l = B(x - 1, y), r = B(x + 1, y), u = B(x, y - 1), d = B(x, y + 1), ul = B(x - 1, y - 1);
+            const float dx = l - c;
+            const float dy = u - c;
+            const float dxx = (l + (-2.0f * c)) + r;
+            const float dyy = (u + (-2.0f * c)) + d;
+            const float dxy = ((ul - u) - l) + c;
+            acc = steger_point(dx, dy, dxx, dyy, dxy, ox, oy);
+        }
+        const unsigned long long m = __ballot(acc);
+        const size_t cell = cell_base + (size_t)y * a.ntx + blockIdx.x;
+        if (acc) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            cells[cell * TW + rank] = make_float2((float)((double)x + ox + (double)a.x0), (float)((double)y + oy + (double)a.y0));
+        }
+        if (lane == 0) cell_counts[cell] = __popcll(m);
+    }
+}
+
+// one block per image: exclusive scan of the cell counts in raster order, then gather
+__global__ void __launch_bounds__(1024) k_steger_compact(int ncells, const float2 *__restrict__ cells, const int *__restrict__ cell_counts,
+                                                         int *__restrict__ cell_offsets, float2 *__restrict__ out, int capacity, int *__restrict__ counts)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *cc = cell_counts + (size_t)b * ncells;
+    int *co = cell_offsets + (size_t)b * ncells;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ncells; base += 1024) {
+        const int i = base + tid;
+        const int v = i < ncells ? cc[i] : 0;
+        int s = v; // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(s, o);
+            if (lane >= o) s += t;
+        }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wv; w++) pre += wsum[w];
+        if (i < ncells) co[i] = pre + s - v;
+        __syncthreads();
+        if (tid == 1023) carry = pre + s;
+        __syncthreads();
+    }
+    if (tid == 0) counts[b] = carry;
+    // gather: one wave per cell
+    const float2 *cs = cells + (size_t)b * ncells * TW;
+    float2 *o = out + (size_t)b * capacity;
+    for (int c = wv; c < ncells; c += 16) {
+        const int n = cc[c], off = co[c];
+        if (lane < n && off + lane < capacity) o[off + lane] = cs[(size_t)c * TW + lane];
+    }
+}
+
+} // namespace l3d
+
+using namespace l3d;
+
+struct l3d_steger {
+    int device = 0, max_w = 0, max_h = 0, max_batch = 0;
+    double sigma = 3.0;
+    int thr = 200, R = 12;
+    hipStream_t stream = nullptr;
+    float *taps = nullptr;
+    float2 *cells = nullptr;
+    int *cell_counts = nullptr, *cell_offsets = nullptr;
+    // staging for the host entry point
+    uint8_t *in = nullptr;
+    float2 *out = nullptr;
+    int *counts = nullptr;
+    size_t max_cells = 0;
+};
+
+extern "C" void l3d_steger_destroy(l3d_steger *h)
+{
+    if (!h) return;
+    DeviceGuard dg(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->taps, h->cells, h->cell_counts, h->cell_offsets, h->in, h->out, h->counts};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int l3d_steger_create(double sigma, int brightness_threshold, int max_width, int max_height, int max_batch, int device,
+                                 l3d_steger **out)
+{
+    L3D_REQUIRE(out, "l3d_steger_create: null argument");
+    *out = nullptr;
+    L3D_REQUIRE(sigma > 0 && max_width > 0 && max_height > 0 && max_batch > 0, "l3d_steger_create: bad argument");
+    // cv::GaussianBlur on a float image with ksize (0,0): ksize = round(sigma*4*2 + 1) | 1
+    const int ks = (int)std::nearbyint(sigma * 4 * 2 + 1) | 1;
+    if (ks > MAX_TAPS) {
+        set_error("l3d_steger_create: sigma %.3f needs a %d-tap kernel (max %d)", sigma, ks, MAX_TAPS);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("l3d_steger_create: no HIP device available");
+        return L3D_ERR_NO_DEVICE;
+    }
+    L3D_REQUIRE(device >= 0 && device < ndev, "l3d_steger_create: device %d out of range", device);
+    l3d_steger *h = new (std::nothrow) l3d_steger();
+    L3D_REQUIRE(h, "l3d_steger_create: out of host memory");
+    h->device = device; h->max_w = max_width; h->max_h = max_height; h->max_batch = max_batch;
+    h->sigma = sigma; h->thr = brightness_threshold; h->R = ks / 2;
+    // cv::getGaussianKernel(ks, sigma, CV_32F): exp(-x^2 / 2 sigma^2) normalised in double
+    std::vector<double> t(ks);
+    double sum = 0;
+    const double scale2x = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ks; i++) {
+        const double x = i - (ks - 1) * 0.5;
+        t[i] = std::exp(scale2x * x * x);
+        sum += t[i];
+    }
+    std::vector<float> tf(ks);
+    for (int i = 0; i < ks; i++) tf[i] = (float)(t[i] * (1.0 / sum));
+    DeviceGuard dg(device);
+    const size_t B = (size_t)max_batch;
+    h->max_cells = (size_t)max_height * cdiv(max_width, TW);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    auto alloc = [&](void **ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void **)&h->taps, MAX_TAPS * sizeof(float));
+    alloc((void **)&h->cells, B * h->max_cells * TW * sizeof(float2));
+    alloc((void **)&h->cell_counts, B * h->max_cells * sizeof(int));
+    alloc((void **)&h->cell_offsets, B * h->max_cells * sizeof(int));
+    alloc((void **)&h->in, B * (size_t)max_width * max_height * 3);
+    alloc((void **)&h->out, B * (size_t)max_width * max_height * sizeof(float2));
+    alloc((void **)&h->counts, B * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(h->taps, tf.data(), ks * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("l3d_steger_create: %s", hipGetErrorString(e));
+        l3d_steger_destroy(h);
+        return L3D_ERR_HIP;
+    }
+    *out = h;
+    return L3D_OK;
+}
+
+static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, int H, int B, const int *roi, float *d_xy, int capacity,
+                      int *d_counts, hipStream_t s)
+{
+    StegerArgs a;
+    a.W = W; a.H = H; a.channels = channels;
+    a.x0 = 0; a.y0 = 0; a.rw = W; a.rh = H;
+    if (roi) {
+        // numpy slicing gray[y:y+h, x:x+w] for non-negative x, y
+        L3D_REQUIRE(roi[0] >= 0 && roi[1] >= 0, "steger: negative roi origin is not supported");
+        a.x0 = std::min(roi[0], W); a.y0 = std::min(roi[1], H);
+        a.rw = std::max(0, std::min(W, roi[0] + roi[2]) - a.x0);
+        a.rh = std::max(0, std::min(H, roi[1] + roi[3]) - a.y0);
+    }
+    a.R = h->R; a.thr = h->thr;
+    a.ntx = cdiv(std::max(a.rw, 1), TW);
+    a.nty = cdiv(std::max(a.rh, 1), TH);
+    if (a.rw <= 0 || a.rh <= 0) {
+        L3D_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), s));
+        return L3D_OK;
+    }
+    const int R = a.R;
+    const size_t lds = ((size_t)(TH + 2 + 2 * R) * (TW + 2 + 2 * R) + (size_t)(TH + 2 + 2 * R) * (TW + 2) + (size_t)(TH + 2) * (TW + 2) +
+                        (2 * R + 1) + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_steger_tile, dim3(a.ntx, a.nty, B), dim3(256), lds, s, a, d_img, h->taps, h->cells, h->cell_counts);
+    const int ncells = a.rh * a.ntx;
+    hipLaunchKernelGGL(k_steger_compact, dim3(B), dim3(1024), 0, s, ncells, h->cells, h->cell_counts, h->cell_offsets, (float2 *)d_xy,
+                       capacity, d_counts);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+static int steger_check(l3d_steger *h, int channels, int W, int H, int B, int capacity, const char *who)
+{
+    L3D_REQUIRE(h, "%s: null handle", who);
+    L3D_REQUIRE(channels == 1 || channels == 3, "%s: channels must be 1 or 3, got %d", who, channels);
+    L3D_REQUIRE(W > 0 && H > 0 && W <= h->max_w && H <= h->max_h, "%s: image %dx%d exceeds the handle's %dx%d", who, W, H, h->max_w, h->max_h);
+    L3D_REQUIRE(B >= 1 && B <= h->max_batch, "%s: batch %d outside [1, %d]", who, B, h->max_batch);
+    L3D_REQUIRE(capacity >= 0, "%s: negative capacity", who);
+    L3D_REQUIRE((size_t)H * cdiv(W, TW) <= h->max_cells, "%s: image shape needs more cells than the handle holds", who);
+    return L3D_OK;
+}
+
+extern "C" int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, int channels, int width, int height, int batch,
+                                         const int *roi, float *d_xy, int capacity, int *d_counts, void *stream)
+{
+    int rc = steger_check(h, channels, width, height, batch, capacity, "l3d_steger_extract_device");
+    if (rc) return rc;
+    L3D_REQUIRE(d_img && d_xy && d_counts, "l3d_steger_extract_device: null argument");
+    DeviceGuard dg(h->device);
+    return steger_run(h, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, stream ? (hipStream_t)stream : h->stream);
+}
+
+extern "C" int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, const int *roi,
+                                  float *xy, int capacity, int *counts)
+{
+    int rc = steger_check(h, channels, width, height, batch, capacity, "l3d_steger_extract");
+    if (rc) return rc;
+    L3D_REQUIRE(img && xy && counts, "l3d_steger_extract: null argument");
+    DeviceGuard dg(h->device);
+    hipStream_t s = h->stream;
+    const size_t px = (size_t)width * height;
+    const int cap_dev = (int)std::min<size_t>((size_t)capacity, px);
+    L3D_HIP_CHECK(hipMemcpyAsync(h->in, img, px * channels * batch, hipMemcpyHostToDevice, s));
+    rc = steger_run(h, h->in, channels, width, height, batch, roi, (float *)h->out, cap_dev, h->counts, s);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipMemcpyAsync(counts, h->counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, s));
+    L3D_HIP_CHECK(hipStreamSynchronize(s));
+    bool overflow = false;
+    for (int b = 0; b < batch; b++) {
+        const int n = std::min(counts[b], cap_dev);
+        if (counts[b] > capacity) overflow = true;
+        if (n > 0) L3D_HIP_CHECK(hipMemcpy(xy + (size_t)b * capacity * 2, h->out + (size_t)b * cap_dev, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    }
+    if (overflow) {
+        set_error("l3d_steger_extract: more points than capacity %d", capacity);
+        return L3D_ERR_CAPACITY;
+    }
+    return L3D_OK;
+}

@@ -1,0 +1,340 @@
+// Confidence-weighted disparity refinement with the Fast Global Smoother, for gfx950.
+//
+// Replaces cv2.ximgproc.createDisparityWLSFilter(left_matcher).filter(dL, left_gray,
+// disparity_map_right=dR) of the reference (camera/single_usb_stereo_camera.py:280-282, 328-332).
+//
+// All work happens on the valid-disparity sub-image (the columns x >= minD + D of the left view,
+// x < W - (minD + D) of the right view), width rw.  Planes in HBM, per handle:
+//   discL, discR [B][H][rw] f32   depth-discontinuity confidence of each view
+//   u1, u2       [B][H][rw] f32   confidence * disparity and confidence (smoothed in place)
+//   t1, t2       [B][rw][H] f32   the same two planes transposed
+//   cv           [B][H][rw] f32   vertical edge weights  -exp(-|I(y,x) - I(y+1,x)| / sigma)
+//   chT          [B][rw][H] f32   horizontal edge weights, transposed
+//   inter        [B][max(H,rw)][min] f32  normalised upper diagonal of the forward sweep
+//   conf         [B][H][W]  f32   confidence map (x255) in full-image coordinates
+// The smoother's tridiagonal solves are sequential along a line and independent across lines, so
+// both passes run as "one thread per line, lines adjacent in memory": the vertical pass directly,
+// the horizontal pass on transposed planes (LDS tile transposes in between), which keeps every
+// load and store of the sweeps coalesced.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace l3d {
+
+constexpr int DT_W = 64, DT_H = 16; // discontinuity-map tile
+
+// var = box(d^2) - box(d)^2 over (2r+1)^2 with replicated borders of the sub-image,
+// conf = max(0, 1 - rolloff * var); box sums are exact integers.
+__global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ disp, int W, int H, int x0, int rw, int r, float rolloff,
+                                                  float *__restrict__ out)
+{
+    extern __shared__ int smi[];
+    const int GW = DT_W + 2 * r, GH = DT_H + 2 * r;
+    int *tile = smi;                                      // [GH][GW] disparity
+    int *h1 = tile + GH * GW;                             // [GH][DT_W] row sums of d
+    long long *h2 = reinterpret_cast<long long *>(h1 + GH * DT_W + ((GH * GW + GH * DT_W) & 1)); // [GH][DT_W] row sums of d^2
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * DT_W, ty0 = blockIdx.y * DT_H, b = blockIdx.z;
+    const int16_t *d = disp + (size_t)b * W * H;
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int gy = i / GW, gx = i - gy * GW;
+        const int x = min(max(tx0 - r + gx, 0), rw - 1), y = min(max(ty0 - r + gy, 0), H - 1);
+        tile[i] = d[(size_t)y * W + x0 + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < GH * DT_W; i += 256) {
+        const int gy = i / DT_W, x = i - gy * DT_W;
+        int a = 0;
+        long long q = 0;
+        for (int j = 0; j <= 2 * r; j++) {
+            const int v = tile[gy * GW + x + j];
+            a += v;
+            q += (long long)v * v;
+        }
+        h1[i] = a;
+        h2[i] = q;
+    }
+    __syncthreads();
+    const int n = (2 * r + 1) * (2 * r + 1);
+    for (int i = tid; i < DT_H * DT_W; i += 256) {
+        const int ty = i / DT_W, x = i - ty * DT_W;
+        if (tx0 + x >= rw || ty0 + ty >= H) continue;
+        long long a = 0, q = 0;
+        for (int j = 0; j <= 2 * r; j++) {
+            a += h1[(ty + j) * DT_W + x];
+            q += h2[(ty + j) * DT_W + x];
+        }
+        const float m1 = (float)((double)a / n);
+        const float m2 = (float)((double)q / n);
+        const float var = m2 - m1 * m1;
+        const float c = 1.0f - rolloff * var;
+        out[((size_t)b * H + ty0 + ty) * rw + tx0 + x] = c > 0.0f ? c : 0.0f;
+    }
+}
+
+// left-right consistency + discontinuity confidence; fills u1 = conf*dL, u2 = conf, and the
+// vertical / transposed-horizontal edge weights of the guide image
+__global__ void __launch_bounds__(256) k_wls_conf(const int16_t *__restrict__ dL, const int16_t *__restrict__ dR,
+                                                  const uint8_t *__restrict__ guide, const float *__restrict__ lut, int W, int H, int lx0, int rx0,
+                                                  int rw, int thresh, const float *__restrict__ discL, const float *__restrict__ discR,
+                                                  float *__restrict__ u1, float *__restrict__ u2, float *__restrict__ cv, float *__restrict__ chT,
+                                                  float *__restrict__ conf_full)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= rw) return;
+    const size_t img = ((size_t)b * H + y) * W;
+    const size_t sub = ((size_t)b * H + y) * rw;
+    const int j = lx0 + x;
+    const int dl = dL[img + j];
+    const int ridx = j - (dl >> 4);
+    float c = 0.0f;
+    if (ridx >= rx0 && ridx < rx0 + rw) {
+        if (abs(dl + (int)dR[img + ridx]) < thresh) {
+            const float a = discL[sub + x], q = discR[sub + (ridx - rx0)];
+            c = a < q ? a : q;
+        }
+    }
+    c = 255.0f * c;
+    u2[sub + x] = c;
+    u1[sub + x] = c * (float)dl;
+    conf_full[img + j] = c;
+    const int g0 = guide[img + j];
+    cv[sub + x] = (y < H - 1) ? lut[abs(g0 - (int)guide[img + W + j])] : 0.0f;
+    chT[((size_t)b * rw + x) * H + y] = (x < rw - 1) ? lut[abs(g0 - (int)guide[img + j + 1])] : 0.0f;
+}
+
+// out[b][c][r] = in[b][r][c] for two planes at once; 32x32 tiles through LDS
+__global__ void __launch_bounds__(256) k_transpose2(const float *__restrict__ in1, const float *__restrict__ in2, int rows, int cols,
+                                                    float *__restrict__ out1, float *__restrict__ out2)
+{
+    __shared__ float t1[32][33], t2[32][33];
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)rows * cols;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            t1[k][tx] = in1[b * plane + (size_t)r * cols + c];
+            t2[k][tx] = in2[b * plane + (size_t)r * cols + c];
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) {
+            out1[b * plane + (size_t)c * rows + r] = t1[tx][k];
+            out2[b * plane + (size_t)c * rows + r] = t2[tx][k];
+        }
+    }
+}
+
+// Thomas algorithm down every column of a [B][n][m] plane pair (m lines of length n, adjacent
+// lines adjacent in memory).  w[i] is the (negative) weight between element i and i+1.
+__global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
+                                                  float *__restrict__ inter, int n, int m, float lambda)
+{
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (line >= m) return;
+    const size_t base = (size_t)b * n * m + line;
+    float *a1 = u1 + base, *a2 = u2 + base, *it = inter + base;
+    const float *ww = w + base;
+    float lower = 0.0f, prev_inter = 0.0f, p1 = 0.0f, p2 = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const size_t o = (size_t)i * m;
+        const float upper = lambda * ww[o];
+        const float denom = (1.0f - lower - upper) - lower * prev_inter;
+        const float ci = upper / denom;
+        const float v1 = (a1[o] - lower * p1) / denom;
+        const float v2 = (a2[o] - lower * p2) / denom;
+        it[o] = ci;
+        a1[o] = v1;
+        a2[o] = v2;
+        prev_inter = ci; p1 = v1; p2 = v2;
+        lower = upper;
+    }
+    for (int i = n - 2; i >= 0; i--) {
+        const size_t o = (size_t)i * m;
+        const float ci = it[o];
+        p1 = a1[o] - ci * p1;
+        p2 = a2[o] - ci * p2;
+        a1[o] = p1;
+        a2[o] = p2;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wls_final(const float *__restrict__ u1, const float *__restrict__ u2, int W, int H, int lx0, int rw,
+                                                   int fill, int16_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    int iv = fill;
+    const int xs = x - lx0;
+    if (xs >= 0 && xs < rw) {
+        const size_t sub = ((size_t)b * H + y) * rw + xs;
+        const float t = 1.0f / (u2[sub] + 1e-43f);
+        const float v = u1[sub] * t;
+        if (!(v == v)) iv = -32768;
+        else if (v >= 32767.0f) iv = 32767;
+        else if (v <= -32768.0f) iv = -32768;
+        else iv = (int)rintf(v);
+    }
+    out[((size_t)b * H + y) * W + x] = (int16_t)iv;
+}
+
+__global__ void __launch_bounds__(256) k_fill_f32(float *p, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+} // namespace l3d
+
+using namespace l3d;
+
+struct l3d_wls {
+    l3d_wls_params p;
+    int W = 0, H = 0, device = 0, max_batch = 0, last_batch = 0;
+    int lx0 = 0, rx0 = 0, rw = 0;
+    hipStream_t stream = nullptr;
+    float *lut = nullptr, *discL = nullptr, *discR = nullptr, *u1 = nullptr, *u2 = nullptr, *t1 = nullptr, *t2 = nullptr;
+    float *cv = nullptr, *chT = nullptr, *inter = nullptr, *conf = nullptr;
+    int16_t *in_l = nullptr, *in_r = nullptr, *out = nullptr;
+    uint8_t *in_g = nullptr;
+};
+
+extern "C" void l3d_wls_destroy(l3d_wls *h)
+{
+    if (!h) return;
+    DeviceGuard dg(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->lut, h->discL, h->discR, h->u1, h->u2, h->t1, h->t2, h->cv, h->chT, h->inter, h->conf, h->in_l, h->in_r, h->out, h->in_g};
+    for (void *q : bufs)
+        if (q) (void)hipFree(q);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int l3d_wls_create(const l3d_wls_params *p, int width, int height, int max_batch, int device, l3d_wls **out)
+{
+    L3D_REQUIRE(p && out, "l3d_wls_create: null argument");
+    *out = nullptr;
+    L3D_REQUIRE(width > 0 && height > 0 && max_batch > 0, "l3d_wls_create: bad size");
+    L3D_REQUIRE(p->lambda >= 0 && p->sigma_color > 0 && p->fgs_iters >= 1, "l3d_wls_create: bad lambda / sigma_color / iterations");
+    L3D_REQUIRE(p->disc_radius >= 0 && p->disc_radius <= 16, "l3d_wls_create: disc_radius %d outside [0, 16]", p->disc_radius);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("l3d_wls_create: no HIP device available");
+        return L3D_ERR_NO_DEVICE;
+    }
+    L3D_REQUIRE(device >= 0 && device < ndev, "l3d_wls_create: device %d out of range", device);
+    l3d_wls *h = new (std::nothrow) l3d_wls();
+    L3D_REQUIRE(h, "l3d_wls_create: out of host memory");
+    h->p = *p; h->W = width; h->H = height; h->device = device; h->max_batch = max_batch;
+    h->lx0 = std::max(0, p->min_disparity + p->num_disparities);
+    h->rx0 = std::max(0, -p->min_disparity);
+    h->rw = width - h->lx0 - h->rx0;
+    DeviceGuard dg(device);
+    const size_t B = (size_t)max_batch, px = (size_t)width * height;
+    const size_t sub = h->rw > 0 ? B * height * (size_t)h->rw : 0;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    auto alloc = [&](void **ptr, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void **)&h->lut, 256 * sizeof(float));
+    float **planes[] = {&h->discL, &h->discR, &h->u1, &h->u2, &h->t1, &h->t2, &h->cv, &h->chT, &h->inter};
+    for (float **pl : planes) alloc((void **)pl, sub * sizeof(float));
+    alloc((void **)&h->conf, B * px * sizeof(float));
+    alloc((void **)&h->in_l, B * px * 2);
+    alloc((void **)&h->in_r, B * px * 2);
+    alloc((void **)&h->out, B * px * 2);
+    alloc((void **)&h->in_g, B * px);
+    if (e == hipSuccess) {
+        // edge-weight table of the smoother: -exp(-|difference| / sigma_color)
+        std::vector<float> lut(256);
+        for (int i = 0; i < 256; i++) lut[i] = (float)(-std::exp(-std::sqrt((double)(i * i)) / (float)p->sigma_color));
+        e = hipMemcpy(h->lut, lut.data(), 256 * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        set_error("l3d_wls_create: %s", hipGetErrorString(e));
+        l3d_wls_destroy(h);
+        return L3D_ERR_HIP;
+    }
+    *out = h;
+    return L3D_OK;
+}
+
+static int wls_run(l3d_wls *h, const int16_t *dL, const int16_t *dR, const uint8_t *guide, int B, int16_t *out, hipStream_t s)
+{
+    const int W = h->W, H = h->H, rw = h->rw, r = h->p.disc_radius;
+    h->last_batch = B;
+    const int fill = 16 * (h->p.min_disparity - 1);
+    const size_t npx = (size_t)B * W * H;
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, h->conf, npx, 0.0f);
+    if (rw > 0) {
+        const int GW = DT_W + 2 * r, GH = DT_H + 2 * r;
+        const size_t lds = (size_t)(GH * GW + GH * DT_W + 1) * sizeof(int) + (size_t)GH * DT_W * sizeof(long long);
+        dim3 gd(cdiv(rw, DT_W), cdiv(H, DT_H), B);
+        hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dL, W, H, h->lx0, rw, r, h->p.disc_rolloff, h->discL);
+        hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dR, W, H, h->rx0, rw, r, h->p.disc_rolloff, h->discR);
+        hipLaunchKernelGGL(k_wls_conf, dim3(cdiv(rw, 256), H, B), dim3(256), 0, s, dL, dR, guide, h->lut, W, H, h->lx0, h->rx0, rw,
+                           h->p.lrc_thresh, h->discL, h->discR, h->u1, h->u2, h->cv, h->chT, h->conf);
+        float lambda = (float)h->p.lambda;
+        const dim3 tg_fwd(cdiv(rw, 32), cdiv(H, 32), B), tg_bwd(cdiv(H, 32), cdiv(rw, 32), B);
+        for (int it = 0; it < h->p.fgs_iters; it++) {
+            // horizontal pass on the transposed planes: H lines of length rw
+            hipLaunchKernelGGL(k_transpose2, tg_fwd, dim3(256), 0, s, h->u1, h->u2, H, rw, h->t1, h->t2);
+            hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->t1, h->t2, h->chT, h->inter, rw, H, lambda);
+            hipLaunchKernelGGL(k_transpose2, tg_bwd, dim3(256), 0, s, h->t1, h->t2, rw, H, h->u1, h->u2);
+            // vertical pass: rw lines of length H
+            hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(rw, 64), B), dim3(64), 0, s, h->u1, h->u2, h->cv, h->inter, H, rw, lambda);
+            lambda *= h->p.fgs_attenuation;
+        }
+    }
+    hipLaunchKernelGGL(k_wls_final, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, h->u1, h->u2, W, H, h->lx0, std::max(rw, 0), fill, out);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_wls_filter_device(l3d_wls *h, const int16_t *d_disp_left, const int16_t *d_disp_right, const uint8_t *d_guide, int batch,
+                                     int16_t *d_out, void *stream)
+{
+    L3D_REQUIRE(h && d_disp_left && d_disp_right && d_guide && d_out, "l3d_wls_filter_device: null argument");
+    L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_wls_filter_device: batch %d outside [1, %d]", batch, h->max_batch);
+    DeviceGuard dg(h->device);
+    return wls_run(h, d_disp_left, d_disp_right, d_guide, batch, d_out, stream ? (hipStream_t)stream : h->stream);
+}
+
+extern "C" int l3d_wls_filter(l3d_wls *h, const int16_t *disp_left, const int16_t *disp_right, const uint8_t *guide, int batch, int16_t *out)
+{
+    L3D_REQUIRE(h && disp_left && disp_right && guide && out, "l3d_wls_filter: null argument");
+    L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_wls_filter: batch %d outside [1, %d]", batch, h->max_batch);
+    DeviceGuard dg(h->device);
+    hipStream_t s = h->stream;
+    const size_t npx = (size_t)batch * h->W * h->H;
+    L3D_HIP_CHECK(hipMemcpyAsync(h->in_l, disp_left, npx * 2, hipMemcpyHostToDevice, s));
+    L3D_HIP_CHECK(hipMemcpyAsync(h->in_r, disp_right, npx * 2, hipMemcpyHostToDevice, s));
+    L3D_HIP_CHECK(hipMemcpyAsync(h->in_g, guide, npx, hipMemcpyHostToDevice, s));
+    int rc = wls_run(h, h->in_l, h->in_r, h->in_g, batch, h->out, s);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipMemcpyAsync(out, h->out, npx * 2, hipMemcpyDeviceToHost, s));
+    L3D_HIP_CHECK(hipStreamSynchronize(s));
+    return L3D_OK;
+}
+
+extern "C" int l3d_wls_fetch_confidence(l3d_wls *h, float *host_dst, size_t bytes)
+{
+    L3D_REQUIRE(h && host_dst, "l3d_wls_fetch_confidence: null argument");
+    const size_t avail = (size_t)h->last_batch * h->W * h->H * sizeof(float);
+    L3D_REQUIRE(bytes <= avail, "l3d_wls_fetch_confidence: %zu bytes requested, %zu available", bytes, avail);
+    DeviceGuard dg(h->device);
+    L3D_HIP_CHECK(hipDeviceSynchronize());
+    L3D_HIP_CHECK(hipMemcpy(host_dst, h->conf, bytes, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
