@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the stereo-depth + laser centre-line hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic rectified
+frame pairs that already sit in HBM:  BGR->gray (both views) -> SGBM-3WAY with the
+reference's constructor parameters (D=64, block=5, uniqueness 10, LR check,
+median, speckle filter) -> /16 + reprojectImageTo3D Z + masks -> Steger
+(sigma=3) on the left BGR frame.  This is BASELINE.json's configs[1]
+("640x360 D=64 block=5 + Steger") and the metric is stereo frame-pairs/s.
+
+For N > 1 launch with torch.distributed.run (one rank per GPU).  Frames shard
+across ranks with no data-path collective; rank 0 broadcasts the calibration (Q)
+once at start-up.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (W, H, D, block, use_wls, lambda, sigma)
+    "C2": (640, 360, 64, 5, False, 8000.0, 1.5),
+    "C3": (1280, 720, 96, 9, True, 10000.0, 1.5),
+    "C5": (1920, 1080, 128, 11, True, 8000.0, 1.5),
+}
+
+
+def alg_bytes(W, H, D, use_wls, n_pts):
+    """Algorithmic HBM bytes per frame pair: one SGBM pass = two u8 inputs + s16 output + one
+    write and one read of the s16 cost volume = 4*W*H*(1+D); WLS adds a second pass + 103*W*H;
+    reprojection 16*W*H; Steger 3*W*H + 8*n_pts."""
+    sgbm = 4 * W * H * (1 + D)
+    total = sgbm + 16 * W * H + 3 * W * H + 8 * n_pts
+    if use_wls:
+        total += sgbm + 103 * W * H
+    return sgbm, total
+
+
+def make_Q(W, H):
+    # reprojection matrix of the reference's calibration (fx ~ 209 px at 320 px width, 62.7 mm baseline), scaled to W
+    f = 209.02533991591997 * (W / 320.0)
+    return np.array([[1, 0, 0, -(W - 1) / 2.0], [0, 1, 0, -(H - 1) / 2.0], [0, 0, 0, f], [0, 0, 15.941451590053976, 0]], np.float64)
+
+
+def cpu_baseline(W, H, D, block, use_wls, lam, sigma, seconds_budget=12.0):
+    """The CPU oracle (a port of the same algorithms, single thread) on a bounded sample of the workload."""
+    from oracle import oracle as O
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    p = O.sgbm_params(numDisparities=D, blockSize=block)
+    Q = make_Q(W, H)
+    n, t_total = 0, 0.0
+    while t_total < seconds_budget and n < 64:
+        lb, rb, _ = S.stereo_pair(W, H, D, 1000 + n)
+        t0 = time.perf_counter()
+        gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+        if use_wls:
+            pl = O.wls_left_matcher_params(p)
+            dl = O.sgbm_compute(pl, gl, gr)
+            dr = O.sgbm_compute(O.right_matcher_params(p), gr, gl)
+            d = O.wls_filter(O.wls_params(p, lam, sigma), dl, dr, gl)
+        else:
+            d = O.sgbm_compute(p, gl, gr)
+        O.depth_from_disp16(d, Q)
+        O.steger_extract(lb, 3.0, 200)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": n / t_total, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} synthetic {W}x{H} D={D} pairs, same stages as the GPU step, one thread of the C oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs per step per GPU")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from laser_3d_reconstruction_amd import ops, parallel, stereo
+    from laser_3d_reconstruction_amd.core.laser_extractor import FastStegerExtractor
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    W, H, D, block, use_wls, lam, sigma = CONFIGS[args.config]
+    B = args.batch
+
+    # start-up: rank 0 owns the calibration and broadcasts it (the only collective of the job)
+    calib = {"Q": make_Q(W, H)} if rank == 0 else None
+    calib = parallel.broadcast_calibration(calib, src=0, device=dev)
+    Q = calib["Q"]
+
+    # synthetic frames of this rank's shard, uploaded once
+    n_distinct = min(B, 16)
+    frames = [S.stereo_pair(W, H, D, k) for k in parallel.shard_indices(n_distinct * world, rank, world)]
+    lbgr = np.stack([frames[i % n_distinct][0] for i in range(B)])
+    rbgr = np.stack([frames[i % n_distinct][1] for i in range(B)])
+    d_l = torch.from_numpy(lbgr).to(dev)
+    d_r = torch.from_numpy(rbgr).to(dev)
+
+    left = stereo.StereoSGBM_create(minDisparity=0, numDisparities=D, blockSize=block, P1=8 * 3 * block ** 2,
+                                    P2=32 * 3 * block ** 2, disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100,
+                                    speckleRange=32, preFilterCap=63, mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY,
+                                    device=local_rank, max_batch=B)
+    right = wls = None
+    if use_wls:
+        right = stereo.createRightMatcher(left)
+        wls = stereo.createDisparityWLSFilter(left)
+        wls.setLambda(lam)
+        wls.setSigmaColor(sigma)
+    steger = FastStegerExtractor(3.0, 200, device=local_rank)
+    cap = 4 * H  # points kept per frame (the synthetic ridge yields ~1.6 per row)
+
+    gl = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    gr = torch.empty_like(gl)
+    disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+    dr_ = torch.empty_like(disp)
+    df_ = torch.empty_like(disp)
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    state = {}
+
+    def step():
+        ops.bgr2gray_device(d_l, gl)
+        ops.bgr2gray_device(d_r, gr)
+        left.compute_device(gl, gr, disp)
+        d = disp
+        if use_wls:
+            right.compute_device(gr, gl, dr_)
+            d = wls.filter_device(disp, gl, dr_, df_)
+        ops.depth_from_disparity16_device(d, Q, depth)
+        state["xy"], state["counts"] = steger.extract_device(d_l, cap)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    left.profile(True)
+    if right is not None:
+        right.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = left.profile_read()
+    left.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_pts = float(state["counts"].float().mean().item())
+    value = B * world * args.steps / elapsed
+
+    # Steger alone (Mpix/s over all pixels), outside the timed region
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        steger.extract_device(d_l, cap)
+    torch.cuda.synchronize()
+    steger_mpix = 10 * B * W * H / (time.perf_counter() - t1) / 1e6
+
+    if rank == 0:
+        sgbm_b, total_b = alg_bytes(W, H, D, use_wls, n_pts)
+        calls = max(prof.pop("calls"), 1)
+        kernel_ms = {k: v / calls for k, v in prof.items()}
+        dom = max(kernel_ms, key=kernel_ms.get)
+        # algorithmic bytes of one launch of each SGBM kernel (B frame pairs): the vertical kernel reads the two
+        # images and writes the cost volume once, the horizontal kernel reads it once and writes the disparity
+        per_kernel_bytes = {
+            "k_prefilter": 2 * W * H * B,
+            "k_cost_vertical": (2 * W * H + 2 * W * H * D) * B,
+            "k_horizontal": (2 * W * H * D + 2 * W * H) * B,
+            "k_lrcheck": 2 * W * H * B,
+            "k_median3": 4 * W * H * B,
+            "k_speckle_*": 4 * W * H * B,
+        }
+        achieved = per_kernel_bytes[dom] / (kernel_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "stereo frame-pairs/sec @640x360 D=64" if args.config == "C2" else f"stereo frame-pairs/sec {args.config}",
+            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "s16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H} rectified pairs, SGBM-3WAY D={D} block={block}"
+                                   + (f" + right matcher + WLS lambda={lam:g}" if use_wls else "")
+                                   + " + depth + Steger sigma=3.0", "batch_per_gpu": B, "sharding": f"frames x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic},
+            "pipeline_roofline": {"alg_bytes_per_pair": total_b, "achieved_GBps": total_b * value / world / 1e9,
+                                  "frac": total_b * value / world / 8e12},
+            "kernel_ms_per_launch": kernel_ms,
+            "steger_mpix_per_s": steger_mpix, "steger_points_per_frame": n_pts,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(W, H, D, block, use_wls, lam, sigma)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

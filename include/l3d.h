@@ -13,12 +13,14 @@
  * Conventions
  *   - "host" entry points take caller-owned host buffers and copy in/out.
  *   - "_device" entry points take device pointers that are already resident in
- *     HBM ([batch][H][W] contiguous) and enqueue on `stream` (a hipStream_t
- *     passed as void*; NULL = the handle's own stream).  They do not
- *     synchronise; the host variants do.
+ *     HBM ([batch][H][W] contiguous) and enqueue on exactly the `stream` given
+ *     (a hipStream_t passed as void*; NULL = HIP's default stream), so they are
+ *     ordered with the caller's own work on that stream.  They do not
+ *     synchronise; the host variants run on the handle's stream and do.
  *   - A handle owns all scratch memory it needs (allocated at create time for
- *     `max_batch` frames) and one stream.  A handle is not thread-safe; distinct
- *     handles are independent.
+ *     `max_batch` frames) and one stream.  A handle is not thread-safe, and two
+ *     calls on one handle must not overlap in time (they share its scratch);
+ *     distinct handles are independent.
  *   - Images are single-channel u8 unless stated; disparities are int16 fixed
  *     point with 4 fractional bits, exactly as cv2.StereoSGBM.compute returns.
  */
@@ -88,6 +90,17 @@ int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d
  *   2 = disparity before median   [batch][H][W]     int16
  * bytes must not exceed the stage's size for the last batch. */
 int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size_t bytes);
+/* Per-kernel device timing of the compute calls on this handle, taken with HIP
+ * events recorded on the stream the kernels are launched on.  profile(h, 1)
+ * switches recording on and clears the totals, profile(h, 0) switches it off;
+ * profile_read waits for outstanding calls and returns the accumulated
+ * milliseconds per kernel (profile_kernel_count entries, named by
+ * profile_kernel_name) and the number of compute calls covered.  No reference
+ * counterpart: measurement only. */
+int l3d_sgbm_profile(l3d_sgbm *h, int enable);
+int l3d_sgbm_profile_read(l3d_sgbm *h, double *total_ms, int n, long *calls);
+const char *l3d_sgbm_profile_kernel_name(int k);
+int l3d_sgbm_profile_kernel_count(void);
 /* out8 = {minX1, W1, stripe_sz, stripe_overlap, invalid16, ftzero, P1, P2} */
 int l3d_sgbm_geometry(const l3d_sgbm_params *params, int width, int height, int *out8);
 

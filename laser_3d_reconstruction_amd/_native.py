@@ -61,6 +61,19 @@ def _load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback."
         )
+    # One process can hold only one HIP runtime (SONAME libamdhip64.so.7).  PyTorch wheels bundle
+    # their own copy; if the system copy were loaded first, a later `import torch` would find no
+    # GPU.  So bind to PyTorch's copy when PyTorch is installed, without importing torch itself.
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i, sz, ss = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
     pi = C.POINTER(C.c_int)
@@ -74,6 +87,10 @@ def _load():
         "l3d_sgbm_compute_device": (i, [vp, vp, vp, i, vp, vp]),
         "l3d_sgbm_fetch_stage": (i, [vp, i, vp, sz]),
         "l3d_sgbm_geometry": (i, [C.POINTER(SgbmParams), i, i, pi]),
+        "l3d_sgbm_profile": (i, [vp, i]),
+        "l3d_sgbm_profile_read": (i, [vp, C.POINTER(C.c_double), i, C.POINTER(C.c_long)]),
+        "l3d_sgbm_profile_kernel_name": (C.c_char_p, [i]),
+        "l3d_sgbm_profile_kernel_count": (i, []),
         "l3d_wls_create": (i, [C.POINTER(WlsParams), i, i, i, i, C.POINTER(vp)]),
         "l3d_wls_destroy": (None, [vp]),
         "l3d_wls_filter": (i, [vp, vp, vp, vp, i, vp]),

@@ -10,6 +10,22 @@ import numpy as np
 from .. import _native as N
 
 
+class SimpleLaserExtractor:
+    """HSV + brightness threshold extractor (core/laser_extractor.py:14-100).  Filled in below."""
+
+    def __init__(self, hsv_lower=None, hsv_upper=None, brightness_threshold=100, min_area=50, device: int = 0,
+                 verbose: bool = False):
+        self.hsv_lower = np.asarray(hsv_lower if hsv_lower is not None else [40, 50, 100])
+        self.hsv_upper = np.asarray(hsv_upper if hsv_upper is not None else [80, 255, 255])
+        self.brightness_threshold = brightness_threshold
+        self.min_area = min_area
+        self.device = device
+        self.verbose = verbose
+
+    def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
+        raise NotImplementedError("SimpleLaserExtractor GPU path is not built yet")
+
+
 class FastStegerExtractor:
     """Steger ridge extractor.  ``extract_centerline(image, roi=None)`` returns the
     list of (x, y) sub-pixel centres in raster order, one entry per accepted

@@ -15,7 +15,7 @@
 //   dsub   [B][H][W1]     s16     sub-pixel disparity (x16) of the column
 //   raw    [B][H][W]      s16     disparity after the left-right check
 //   med    [B][H][W]      s16     after the 3x3 median (speckle filter runs in place on the output)
-//   labels [B][H][W]      s32     union-find parents of the speckle filter, sizes [B][H][W] s32
+//   labels [B][H][W]      s32     union-find parents of the speckle filter; sizes, tsizes [B][H][W] s32
 //
 // Work decomposition: a disparity vector of one pixel lives in one DPP row (16 lanes); each lane
 // holds 2*NP consecutive disparities as NP packed int16 pairs (D = 32*NP), so the d-1 / d+1
@@ -475,9 +475,33 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6: speckle filter = connected components (4-neighbourhood, |a-b| <= maxDiff) by lock-free
-// union-find, then size threshold.
+// K6: speckle filter = connected components (4-neighbourhood, |a-b| <= maxDiff, pixels equal to
+// newVal excluded), components of at most maxSize pixels are set to newVal.
+// Two-level union-find: each 32x32 tile is labelled and counted in LDS (LDS atomics, no global
+// contention); tile roots are then merged across tile borders in global memory and the tile
+// counts are summed onto the final roots, so global atomics scale with the tile perimeter and
+// the number of tile-level components, not with the pixel count.
 // ---------------------------------------------------------------------------------------------
+constexpr int ST = 32; // speckle tile edge
+
+__device__ __forceinline__ int lds_find(volatile int *L, int i)
+{
+    int r = i, p;
+    while ((p = L[r]) != r) r = p;
+    return r;
+}
+__device__ __forceinline__ void lds_union(int *L, int a, int b)
+{
+    while (true) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(L + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
 __device__ __forceinline__ int uf_load(const int *L, int i) { return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int uf_find(const int *L, int i)
 {
@@ -498,42 +522,100 @@ __device__ __forceinline__ void uf_union(int *L, int a, int b)
     }
 }
 
-__global__ void __launch_bounds__(256) k_speckle_init(const int16_t *__restrict__ disp, size_t n, int newVal, int *__restrict__ labels, int *__restrict__ sizes)
+// labels[i] = global index of the tile-level root of pixel i (-1 for excluded pixels);
+// tsize[i] = fsize[i] = pixel count of the tile-level component rooted at i (0 elsewhere)
+__global__ void __launch_bounds__(256) k_speckle_tile(const int16_t *__restrict__ disp, int W, int H, int newVal, int maxDiff,
+                                                      int *__restrict__ labels, int *__restrict__ tsize, int *__restrict__ fsize)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    labels[i] = (disp[i] != newVal) ? (int)i : -1;
-    sizes[i] = 0;
+    __shared__ int lab[ST * ST];
+    __shared__ int cnt[ST * ST];
+    __shared__ short dv[ST * ST];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * ST;
+    const size_t img = (size_t)blockIdx.z * W * H;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
+        const int gx = tx0 + x, gy = ty0 + y;
+        const int v = (gx < W && gy < H) ? (int)disp[img + (size_t)gy * W + gx] : newVal;
+        dv[idx] = (short)v;
+        lab[idx] = (v != newVal) ? idx : -1;
+        cnt[idx] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
+        const int v = dv[idx];
+        if (v == newVal) continue;
+        if (x < ST - 1) { const int u = dv[idx + 1]; if (u != newVal && abs(v - u) <= maxDiff) lds_union(lab, idx, idx + 1); }
+        if (y < ST - 1) { const int u = dv[idx + ST]; if (u != newVal && abs(v - u) <= maxDiff) lds_union(lab, idx, idx + ST); }
+    }
+    __syncthreads();
+    int root[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = tid + 256 * k;
+        root[k] = -1;
+        if (lab[idx] >= 0) {
+            root[k] = lds_find(lab, idx);
+            atomicAdd(&cnt[root[k]], 1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
+        const int gx = tx0 + x, gy = ty0 + y;
+        if (gx >= W || gy >= H) continue;
+        const size_t g = img + (size_t)gy * W + gx;
+        const int r = root[k];
+        labels[g] = r < 0 ? -1 : (int)(img + (size_t)(ty0 + (r >> 5)) * W + tx0 + (r & (ST - 1)));
+        const int c = (r == idx) ? cnt[idx] : 0;
+        tsize[g] = c;
+        fsize[g] = c;
+    }
 }
-__global__ void __launch_bounds__(256) k_speckle_merge(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int *labels)
+
+// joins tile-level components across tile borders
+__global__ void __launch_bounds__(256) k_speckle_border(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int *labels)
 {
     const size_t n = (size_t)W * H * B;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const bool right = ((x & (ST - 1)) == ST - 1) && x + 1 < W;
+    const bool down = ((y & (ST - 1)) == ST - 1) && y + 1 < H;
+    if (!right && !down) return;
     const int v = disp[i];
     if (v == newVal) return;
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    if (x + 1 < W) { const int u = disp[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + 1); }
-    if (y + 1 < H) { const int u = disp[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + W); }
+    if (right) { const int u = disp[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + 1); }
+    if (down) { const int u = disp[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + W); }
 }
-__global__ void __launch_bounds__(256) k_speckle_count(size_t n, int *labels, int *sizes)
+
+// every tile-level root adds its count to the final root of its component and points at it
+__global__ void __launch_bounds__(256) k_speckle_sum(size_t n, int *labels, const int *__restrict__ tsize, int *fsize)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (labels[i] < 0) return;
-    int r = (int)i, p;
-    while ((p = labels[r]) != r) r = p;
-    labels[i] = r;
-    atomicAdd(sizes + r, 1);
+    const int c = tsize[i];
+    if (c == 0) return;
+    const int r = uf_find(labels, (int)i);
+    if (r != (int)i) {
+        atomicAdd(fsize + r, c);
+        __hip_atomic_store(labels + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-__global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, size_t n, int newVal, int maxSize, const int *__restrict__ labels, const int *__restrict__ sizes)
+
+__global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, size_t n, int newVal, int maxSize, const int *__restrict__ labels, const int *__restrict__ fsize)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int r = labels[i];
-    if (r < 0) return;
-    // k_speckle_count left labels[i] pointing at the root of its component
-    if (sizes[r] <= maxSize) disp[i] = (int16_t)newVal;
+    const int t = labels[i]; // tile-level root of the pixel
+    if (t < 0) return;
+    int r = t, p;
+    while ((p = labels[r]) != r) r = p; // at most a few hops: k_speckle_sum pointed tile roots at final roots
+    if (fsize[r] <= maxSize) disp[i] = (int16_t)newVal;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,9 +660,33 @@ struct l3d_sgbm {
     uint8_t *rrev = nullptr;
     uint32_t *Cvol = nullptr, *Tvol = nullptr, *Lvol = nullptr, *wta = nullptr;
     int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
-    int *labels = nullptr, *sizes = nullptr;
+    int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr;
     size_t lds_vertical = 0;
+    // optional per-kernel timing: a ring of event sets, one set per compute call
+    static constexpr int NK = 6, RING = 32;
+    bool prof = false;
+    hipEvent_t ev[RING][NK + 1] = {};
+    int ev_head = 0, ev_pending = 0;
+    double prof_ms[NK] = {};
+    long prof_calls = 0;
 };
+
+static const char *const k_sgbm_kernel_names[l3d_sgbm::NK] = {"k_prefilter", "k_cost_vertical", "k_horizontal", "k_lrcheck", "k_median3", "k_speckle_*"};
+
+// folds the oldest pending event set into the totals (waits for it to complete)
+static int sgbm_prof_drain_one(l3d_sgbm *h)
+{
+    const int slot = (h->ev_head - h->ev_pending + 2 * l3d_sgbm::RING) % l3d_sgbm::RING;
+    L3D_HIP_CHECK(hipEventSynchronize(h->ev[slot][l3d_sgbm::NK]));
+    for (int k = 0; k < l3d_sgbm::NK; k++) {
+        float ms = 0;
+        L3D_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][k], h->ev[slot][k + 1]));
+        h->prof_ms[k] += ms;
+    }
+    h->prof_calls++;
+    h->ev_pending--;
+    return L3D_OK;
+}
 
 extern "C" int l3d_sgbm_geometry(const l3d_sgbm_params *params, int width, int height, int *out8)
 {
@@ -598,9 +704,12 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Lvol,
-                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes};
+                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    for (auto &set : h->ev)
+        for (hipEvent_t e : set)
+            if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -670,6 +779,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     if (p->speckleWindowSize > 0) {
         alloc((void **)&h->labels, B * px * 4);
         alloc((void **)&h->sizes, B * px * 4);
+        alloc((void **)&h->tsizes, B * px * 4);
     }
     if (e != hipSuccess) {
         set_error("l3d_sgbm_create: allocation failed: %s", hipGetErrorString(e));
@@ -692,12 +802,13 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     return L3D_OK;
 }
 
-template <int NP>
-static void launch_core(l3d_sgbm *h, int B, hipStream_t s)
+template <int NP, typename Stamp>
+static void launch_core(l3d_sgbm *h, int B, hipStream_t s, Stamp &stamp)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 16), 4, B);
     hipLaunchKernelGGL(k_cost_vertical<NP>, gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
+    stamp();
     const int nrows = B * g.H;
     hipLaunchKernelGGL(k_horizontal<NP>, dim3(cdiv(nrows, 4)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
 }
@@ -716,29 +827,49 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
         L3D_HIP_CHECK(hipStreamSynchronize(s));
         return L3D_OK;
     }
+    int slot = -1;
+    if (h->prof) {
+        if (h->ev_pending == l3d_sgbm::RING) {
+            int rc = sgbm_prof_drain_one(h);
+            if (rc) return rc;
+        }
+        slot = h->ev_head;
+        h->ev_head = (h->ev_head + 1) % l3d_sgbm::RING;
+        h->ev_pending++;
+    }
+    int mark = 0;
+    auto stamp = [&]() {
+        if (slot >= 0) (void)hipEventRecord(h->ev[slot][mark++], s);
+    };
+    stamp();
     hipLaunchKernelGGL(k_prefilter, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
+    stamp();
     switch (g.NP) {
-    case 1: launch_core<1>(h, B, s); break;
-    case 2: launch_core<2>(h, B, s); break;
-    case 3: launch_core<3>(h, B, s); break;
-    case 4: launch_core<4>(h, B, s); break;
-    case 5: launch_core<5>(h, B, s); break;
-    case 6: launch_core<6>(h, B, s); break;
-    case 7: launch_core<7>(h, B, s); break;
-    case 8: launch_core<8>(h, B, s); break;
+    case 1: launch_core<1>(h, B, s, stamp); break;
+    case 2: launch_core<2>(h, B, s, stamp); break;
+    case 3: launch_core<3>(h, B, s, stamp); break;
+    case 4: launch_core<4>(h, B, s, stamp); break;
+    case 5: launch_core<5>(h, B, s, stamp); break;
+    case 6: launch_core<6>(h, B, s, stamp); break;
+    case 7: launch_core<7>(h, B, s, stamp); break;
+    case 8: launch_core<8>(h, B, s, stamp); break;
     default: set_error("sgbm: unsupported NP %d", g.NP); return L3D_ERR_UNSUPPORTED;
     }
+    stamp();
     hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(256), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
+    stamp();
     const bool speckle = g.speckleWindowSize > 0;
     hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
+    stamp();
     if (speckle) {
         const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange;
         const unsigned nb = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_speckle_init, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, h->labels, h->sizes);
-        hipLaunchKernelGGL(k_speckle_merge, dim3(nb), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, h->labels);
-        hipLaunchKernelGGL(k_speckle_count, dim3(nb), dim3(256), 0, s, n, h->labels, h->sizes);
+        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, h->labels, h->tsizes, h->sizes);
+        hipLaunchKernelGGL(k_speckle_border, dim3(nb), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, h->labels);
+        hipLaunchKernelGGL(k_speckle_sum, dim3(nb), dim3(256), 0, s, n, h->labels, h->tsizes, h->sizes);
         hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, g.speckleWindowSize, h->labels, h->sizes);
     }
+    stamp();
     L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;
 }
@@ -748,7 +879,7 @@ extern "C" int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const
     L3D_REQUIRE(h && d_left && d_right && d_disp, "l3d_sgbm_compute_device: null argument");
     L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_sgbm_compute_device: batch %d outside [1, %d]", batch, h->max_batch);
     DeviceGuard dg(h->device);
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;
     return sgbm_run(h, d_left, d_right, batch, d_disp, s);
 }
 
@@ -795,3 +926,42 @@ extern "C" int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size
     L3D_HIP_CHECK(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
     return L3D_OK;
 }
+
+extern "C" int l3d_sgbm_profile(l3d_sgbm *h, int enable)
+{
+    L3D_REQUIRE(h, "l3d_sgbm_profile: null handle");
+    DeviceGuard dg(h->device);
+    while (h->ev_pending > 0) {
+        int rc = sgbm_prof_drain_one(h);
+        if (rc) return rc;
+    }
+    if (enable && !h->ev[0][0]) {
+        for (auto &set : h->ev)
+            for (hipEvent_t &e : set) L3D_HIP_CHECK(hipEventCreate(&e));
+    }
+    h->prof = enable != 0;
+    for (double &v : h->prof_ms) v = 0;
+    h->prof_calls = 0;
+    return L3D_OK;
+}
+
+extern "C" int l3d_sgbm_profile_read(l3d_sgbm *h, double *total_ms, int n, long *calls)
+{
+    L3D_REQUIRE(h && total_ms && calls, "l3d_sgbm_profile_read: null argument");
+    L3D_REQUIRE(n >= l3d_sgbm::NK, "l3d_sgbm_profile_read: need room for %d kernels", l3d_sgbm::NK);
+    DeviceGuard dg(h->device);
+    while (h->ev_pending > 0) {
+        int rc = sgbm_prof_drain_one(h);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < l3d_sgbm::NK; k++) total_ms[k] = h->prof_ms[k];
+    *calls = h->prof_calls;
+    return L3D_OK;
+}
+
+extern "C" const char *l3d_sgbm_profile_kernel_name(int k)
+{
+    return (k >= 0 && k < l3d_sgbm::NK) ? k_sgbm_kernel_names[k] : "";
+}
+
+extern "C" int l3d_sgbm_profile_kernel_count(void) { return l3d_sgbm::NK; }

@@ -352,7 +352,7 @@ extern "C" int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, in
     if (rc) return rc;
     L3D_REQUIRE(d_img && d_xy && d_counts, "l3d_steger_extract_device: null argument");
     DeviceGuard dg(h->device);
-    return steger_run(h, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, stream ? (hipStream_t)stream : h->stream);
+    return steger_run(h, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, (hipStream_t)stream);
 }
 
 extern "C" int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, const int *roi,

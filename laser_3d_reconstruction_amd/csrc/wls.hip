@@ -308,7 +308,7 @@ extern "C" int l3d_wls_filter_device(l3d_wls *h, const int16_t *d_disp_left, con
     L3D_REQUIRE(h && d_disp_left && d_disp_right && d_guide && d_out, "l3d_wls_filter_device: null argument");
     L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_wls_filter_device: batch %d outside [1, %d]", batch, h->max_batch);
     DeviceGuard dg(h->device);
-    return wls_run(h, d_disp_left, d_disp_right, d_guide, batch, d_out, stream ? (hipStream_t)stream : h->stream);
+    return wls_run(h, d_disp_left, d_disp_right, d_guide, batch, d_out, (hipStream_t)stream);
 }
 
 extern "C" int l3d_wls_filter(l3d_wls *h, const int16_t *disp_left, const int16_t *disp_right, const uint8_t *guide, int batch, int16_t *out)

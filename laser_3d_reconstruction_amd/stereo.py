@@ -148,6 +148,22 @@ class StereoSGBM:
                 "l3d_sgbm_compute_device")
         return out
 
+    def profile(self, enable: bool = True):
+        """Switch per-kernel HIP-event timing of this matcher's compute calls on/off (clears totals)."""
+        if self._h is None:
+            raise RuntimeError("profile() needs a compute call first (no handle yet)")
+        N.check(N.lib.l3d_sgbm_profile(self._h, int(bool(enable))), "l3d_sgbm_profile")
+
+    def profile_read(self) -> dict:
+        """{kernel name: total milliseconds} plus 'calls' since profile(True)."""
+        n = N.lib.l3d_sgbm_profile_kernel_count()
+        ms = (C.c_double * n)()
+        calls = C.c_long(0)
+        N.check(N.lib.l3d_sgbm_profile_read(self._h, ms, n, C.byref(calls)), "l3d_sgbm_profile_read")
+        out = {N.lib.l3d_sgbm_profile_kernel_name(k).decode(): ms[k] for k in range(n)}
+        out["calls"] = calls.value
+        return out
+
     def fetch_stage(self, stage: int, batch: int, w: int, h: int) -> np.ndarray:
         g = self.geometry(w, h)
         if stage in (0, 1):

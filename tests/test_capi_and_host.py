@@ -1,0 +1,241 @@
+"""CPU tests: the C ABI library loads and exports every symbol include/l3d.h declares, the
+host-side mirror of the reference classes behaves like the reference, and the N>1 plumbing
+works over gloo."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "l3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from laser_3d_reconstruction_amd import _native as N
+
+    lib = C.CDLL(N.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/l3d.h but not exported"
+    assert set(N.EXPORTED) == set(names), set(N.EXPORTED) ^ set(names)
+    assert b"gfx950" in N.lib.l3d_version()
+
+
+def test_entry_points_fail_loudly_without_a_gpu():
+    from laser_3d_reconstruction_amd import _native as N
+
+    if N.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
+    h = C.c_void_p()
+    assert N.lib.l3d_sgbm_create(C.byref(p), 640, 360, 1, 0, C.byref(h)) == -4
+    assert b"no HIP device" in N.lib.l3d_last_error()
+    from laser_3d_reconstruction_amd import stereo
+
+    with pytest.raises(N.L3DError):
+        stereo.StereoSGBM_create(0, 64, 5, mode=2).compute(np.zeros((64, 128), np.uint8), np.zeros((64, 128), np.uint8))
+
+
+def test_argument_validation_needs_no_gpu():
+    from laser_3d_reconstruction_amd import _native as N
+
+    h = C.c_void_p()
+    bad_mode = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 0)
+    assert N.lib.l3d_sgbm_create(C.byref(bad_mode), 640, 360, 1, 0, C.byref(h)) == -2
+    assert b"3WAY" in N.lib.l3d_last_error()
+    bad_d = N.SgbmParams(0, 48, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
+    assert N.lib.l3d_sgbm_create(C.byref(bad_d), 640, 360, 1, 0, C.byref(h)) == -2
+    out = (C.c_int * 8)()
+    ok = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
+    assert N.lib.l3d_sgbm_geometry(C.byref(ok), 640, 360, out) == 0
+    assert list(out) == [64, 576, 90, 12, -16, 63, 600, 2400]
+
+
+def test_geometry_agrees_with_oracle(O):
+    from laser_3d_reconstruction_amd import stereo
+
+    for (w, h, d, b, mind) in [(640, 360, 64, 5, 0), (1280, 720, 96, 9, 0), (1920, 1080, 128, 11, 0), (333, 131, 64, 3, -63)]:
+        m = stereo.StereoSGBM_create(mind, d, b, 8 * 3 * b * b, 32 * 3 * b * b, 1, 63, 10, 100, 32, 2)
+        g = m.geometry(w, h)
+        og = O.sgbm_geometry(O.sgbm_params(minDisparity=mind, numDisparities=d, blockSize=b), w, h)
+        og.pop("rc")
+        assert g == og
+
+
+def test_matcher_factories_follow_opencv():
+    from laser_3d_reconstruction_amd import stereo
+
+    left = stereo.StereoSGBM_create(minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+                                    uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, preFilterCap=63,
+                                    mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY)
+    right = stereo.createRightMatcher(left)
+    assert right.params.as_dict() == dict(minDisparity=-63, numDisparities=64, blockSize=5, P1=600, P2=2400,
+                                          disp12MaxDiff=1000000, preFilterCap=63, uniquenessRatio=0,
+                                          speckleWindowSize=0, speckleRange=0, mode=2)
+    assert left.getUniquenessRatio() == 10 and left.getSpeckleWindowSize() == 100
+    wls = stereo.createDisparityWLSFilter(left)
+    # the factory reconfigures the left matcher exactly as OpenCV's does
+    assert (left.getDisp12MaxDiff(), left.getSpeckleWindowSize(), left.getUniquenessRatio()) == (1000000, 0, 0)
+    assert wls.getDepthDiscontinuityRadius() == 3 and wls.getLRCthresh() == 24 and wls.getLambda() == 8000.0
+    wls.setLambda(10000.0)
+    wls.setSigmaColor(1.5)
+    p = wls.params()
+    assert (p.lambda_, p.sigma_color, p.min_disparity, p.num_disparities, p.fgs_iters) == (10000.0, 1.5, 0, 64, 3)
+
+
+def test_config_keeps_reference_knobs():
+    from laser_3d_reconstruction_amd import Config
+
+    d = Config.to_dict()
+    expect = {
+        "SINGLE_USB_CAMERA_ID": 1, "CAMERA_WIDTH": 640, "CAMERA_HEIGHT": 240, "CAMERA_FPS": 30, "SPLIT_MODE": "horizontal",
+        "STEREO_CALIBRATION_FILE": "stereo_calibration.json", "STEREO_NUM_DISPARITIES": 64, "STEREO_BLOCK_SIZE": 5,
+        "STEREO_USE_WLS_FILTER": True, "STEREO_LAMBDA": 8000.0, "STEREO_SIGMA": 1.5, "LASER_EXTRACTOR_TYPE": "simple",
+        "SIMPLE_LASER_HSV_LOWER": [50, 100, 180], "SIMPLE_LASER_HSV_UPPER": [70, 255, 255],
+        "SIMPLE_LASER_BRIGHTNESS_THRESHOLD": 200, "SIMPLE_LASER_MIN_AREA": 50, "STEGER_SIGMA": 3.0,
+        "STEGER_BRIGHTNESS_THRESHOLD": 200, "STEGER_USE_LUT": True, "LASER_PLANE_COEFFICIENTS": [0, 0, 1, 0],
+        "USE_REFRACTION_CORRECTION": False, "WATER_REFRACTION_INDEX": 1.33, "VOXEL_SIZE": 0.002,
+        "OUTLIER_REMOVAL_NEIGHBORS": 20, "OUTLIER_REMOVAL_STD_RATIO": 2.0, "SAVE_FORMAT": "ply", "DEBUG_MODE": False,
+        "OUTPUT_DIR": "output", "AUTO_SAVE_INTERVAL": 60, "MIN_POINT_CLOUD_SIZE": 100, "JETSON_OPTIMIZED": False,
+        "USE_CUDA": False, "NUM_THREADS": 4,
+    }
+    assert d == expect
+
+
+def test_camera_manager_surface_and_knobs():
+    from laser_3d_reconstruction_amd import Config, SingleUSBStereoCameraManager
+
+    cam = SingleUSBStereoCameraManager()
+    assert (cam.width, cam.height, cam.fps, cam.split_mode, cam.calibration_file) == (640, 240, 30, "horizontal", "stereo_calibration.json")
+    assert (cam.single_width, cam.single_height) == (320, 240)
+    for attr in ("cap", "Q", "P1", "T", "map_left_x", "map_left_y", "map_right_x", "map_right_y", "roi_left", "roi_right",
+                 "stereo_matcher", "right_matcher", "wls_filter"):
+        assert getattr(cam, attr) is None
+    assert cam.get_frames() == (None, None) and cam.initialize() is False and cam.get_camera_intrinsics() is None
+    frame = np.arange(240 * 640 * 3, dtype=np.uint8).reshape(240, 640, 3)
+    l, r = cam._split_frame(frame)
+    assert l.shape == (240, 320, 3) and np.array_equal(r, frame[:, 320:])
+    # width rule of the reference when no Config is given
+    assert cam._matcher_knobs()[:2] == (64, 5)
+    assert SingleUSBStereoCameraManager(width=1280, height=360)._matcher_knobs()[:2] == (96, 7)
+
+    class Knobs(Config):
+        STEREO_NUM_DISPARITIES = 128
+        STEREO_BLOCK_SIZE = 11
+        STEREO_LAMBDA = 10000.0
+
+    cam = SingleUSBStereoCameraManager(width=3840, height=1080, config=Knobs, calibration_file="/nonexistent.json")
+    cam.initialize_offline()
+    assert cam.stereo_matcher.getNumDisparities() == 128 and cam.stereo_matcher.getBlockSize() == 11
+    assert cam.stereo_matcher.getP1() == 8 * 3 * 121 and cam.stereo_matcher.getP2() == 32 * 3 * 121
+    assert cam.wls_filter.getLambda() == 10000.0 and cam.wls_filter.getSigmaColor() == 1.5
+    assert cam.right_matcher.getMinDisparity() == -127
+    assert cam.get_camera_intrinsics()["fx"] == 350.0 and cam.get_camera_intrinsics()["baseline"] == 0.06
+
+
+def test_camera_manager_loads_reference_style_calibration(tmp_path):
+    import json
+    from laser_3d_reconstruction_amd import SingleUSBStereoCameraManager
+
+    calib = {"camera_matrix_left": [[208.9, 0, 166.3], [0, 209.5, 131.2], [0, 0, 1]], "dist_coeffs_left": [-0.06, 0.18, 0, 0, 0],
+             "camera_matrix_right": [[209.2, 0, 174.0], [0, 209.9, 133.1], [0, 0, 1]], "dist_coeffs_right": [-0.04, 0.09, 0, 0, 0],
+             "R": np.eye(3).tolist(), "T": [-0.0627, -0.0001, -0.0004],
+             "P1": [[209.0, 0, 159.5, 0], [0, 209.7, 119.5, 0], [0, 0, 1, 0]],
+             "Q": [[1, 0, 0, -159.5], [0, 1, 0, -119.5], [0, 0, 0, 209.0], [0, 0, -15.94, 0]]}
+    f = tmp_path / "calib.json"
+    f.write_text(json.dumps(calib))
+    cam = SingleUSBStereoCameraManager(calibration_file=str(f))
+    assert cam._load_calibration()
+    k = cam.get_camera_intrinsics()
+    assert k["fx"] == 209.0 and k["cy"] == 119.5 and abs(k["baseline"] - np.linalg.norm(calib["T"])) < 1e-12
+    assert cam.Q.shape == (4, 4)
+
+
+def test_reconstructor_host_helpers():
+    from laser_3d_reconstruction_amd import Reconstructor
+
+    K = np.array([[209.025, 0, 159.5], [0, 209.72, 119.5], [0, 0, 1.0]])
+    r = Reconstructor(K, np.array([0, 0, 1, -0.5]))
+    assert r.water_refraction_index == 1.33 and r.use_refraction is True
+    assert r.reconstruct_laser_line([]).shape == (0,) and r.reconstruct_from_depth([], np.zeros((4, 4), np.float32)).shape == (0,)
+    pts = np.array([[0, 0, 1.0], [0.001, 0, 1.0], [0.5, 0, 1.0], [0.5005, 0, 1.0], [0.501, 0, 1.0]])
+    out = r.filter_outliers(pts, threshold=0.01)
+    np.testing.assert_array_equal(out, pts[[0, 3, 4]])     # same rule as core/reconstruction.py:201-217
+    assert r.filter_outliers(pts[:2]) is not None and len(r.filter_outliers(pts[:2])) == 2
+    R = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    np.testing.assert_allclose(r.transform_points(pts, R, np.array([1, 2, 3.0])), (R @ pts.T).T + [1, 2, 3])
+    assert r.merge_point_clouds([]).shape == (0,) and r.merge_point_clouds([np.array([]), pts]).shape == (5, 3)
+
+
+def test_synthetic_frames_are_deterministic_and_shaped_for_the_extractors(O):
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    a = S.stereo_pair(640, 360, 64, 5)
+    b = S.stereo_pair(640, 360, 64, 5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    lb = a[0]
+    g = O.bgr2gray(lb)
+    hsv = O.bgr2hsv(lb)
+    bright = g > 200
+    assert 500 < bright.sum() < 5000                      # only the ridge is above the Steger threshold
+    inr = (hsv[..., 0] >= 50) & (hsv[..., 0] <= 70) & (hsv[..., 1] >= 100) & (hsv[..., 2] >= 180)
+    assert (inr & bright).sum() > 0.5 * bright.sum()      # and it is green enough for the HSV extractor
+
+
+def test_shard_indices_partition_the_frames():
+    from laser_3d_reconstruction_amd import parallel
+
+    for world in (1, 2, 3, 8):
+        got = sorted(i for r in range(world) for i in parallel.shard_indices(37, r, world))
+        assert got == list(range(37))
+    with pytest.raises(ValueError):
+        parallel.shard_indices(4, 2, 2)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from laser_3d_reconstruction_amd import parallel
+
+    calib = None
+    if rank == 0:
+        calib = {"Q": np.arange(16, dtype=np.float64).reshape(4, 4), "map_left_x": np.random.default_rng(1).random((7, 9), np.float32),
+                 "num_disparities": np.int32(64)}
+    got = parallel.broadcast_calibration(calib, src=0)
+    mine = parallel.shard_indices(10, rank, world)
+    counts = parallel.gather_counts(float(len(mine)))
+    q.put((rank, got["Q"].tolist(), float(got["map_left_x"].sum()), int(got["num_disparities"]), mine, counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_over_gloo_world_size_2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want_sum = float(np.random.default_rng(1).random((7, 9), np.float32).sum())
+    for rank, Q, s, nd, mine, counts in res:
+        assert Q == np.arange(16, dtype=np.float64).reshape(4, 4).tolist() and abs(s - want_sum) < 1e-6 and nd == 64
+        assert mine == list(range(rank, 10, 2)) and counts == [5.0, 5.0]
