@@ -177,6 +177,33 @@ int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, int channels,
                               void *stream);
 
 /* ---------------------------------------------------------------------------
+ * HSV / brightness laser extractor (SimpleLaserExtractor,
+ * core/laser_extractor.py:14-100).
+ * ------------------------------------------------------------------------- */
+typedef struct l3d_simple l3d_simple;
+
+/* replaces SimpleLaserExtractor.__init__ (core/laser_extractor.py:20-43); the
+ * HSV range, threshold and min_area are per-call arguments */
+int l3d_simple_create(int max_width, int max_height, int device, l3d_simple **out);
+void l3d_simple_destroy(l3d_simple *h);
+/* replaces SimpleLaserExtractor.extract_centerline (core/laser_extractor.py:45-100):
+ * cvtColor(BGR2HSV) + inRange, cvtColor(BGR2GRAY) + threshold, bitwise_and,
+ * morphologyEx CLOSE + OPEN (3x3), findContours(RETR_EXTERNAL) + contourArea >
+ * min_area + drawContours(filled), per-row intensity-weighted centroid.
+ * bgr [H][W][3] u8; hsv_lower / hsv_upper 3 ints (inclusive, H in [0,180));
+ * xy receives up to `height` (x, y) pairs of doubles in ascending y, *count how
+ * many.  masks (may be NULL): 3 planes of W*H bytes = combined mask, mask after
+ * morphology, final filled mask (for stage-level checks). */
+int l3d_simple_extract(l3d_simple *h, const uint8_t *bgr, int width, int height, const int *hsv_lower,
+                       const int *hsv_upper, int brightness_threshold, double min_area, double *xy,
+                       int *count, uint8_t *masks);
+/* device-resident image; results still land in host memory (xy, count) after a
+ * synchronisation of `stream` */
+int l3d_simple_extract_device(l3d_simple *h, const uint8_t *d_bgr, int width, int height,
+                              const int *hsv_lower, const int *hsv_upper, int brightness_threshold,
+                              double min_area, double *xy, int *count, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Laser pixel -> 3-D (Reconstructor, core/reconstruction.py).
  * ------------------------------------------------------------------------- */
 /* replaces Reconstructor.reconstruct_from_depth (core/reconstruction.py:145-182).

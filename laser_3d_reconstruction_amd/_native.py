@@ -104,6 +104,10 @@ def _load():
         "l3d_steger_destroy": (None, [vp]),
         "l3d_steger_extract": (i, [vp, vp, i, i, i, i, pi, vp, i, vp]),
         "l3d_steger_extract_device": (i, [vp, vp, i, i, i, i, pi, vp, i, vp, vp]),
+        "l3d_simple_create": (i, [i, i, i, C.POINTER(vp)]),
+        "l3d_simple_destroy": (None, [vp]),
+        "l3d_simple_extract": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
+        "l3d_simple_extract_device": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
         "l3d_reconstruct_from_depth": (i, [vp, i, vp, i, i, vp, vp, pi, i]),
         "l3d_reconstruct_plane": (i, [vp, i, vp, vp, i, C.c_double, vp, i]),
     }

@@ -11,7 +11,10 @@ from .. import _native as N
 
 
 class SimpleLaserExtractor:
-    """HSV + brightness threshold extractor (core/laser_extractor.py:14-100).  Filled in below."""
+    """HSV + brightness threshold extractor (core/laser_extractor.py:14-100):
+    ``extract_centerline(image BGR uint8) -> [(x, y), ...]``, one intensity-weighted
+    centre per image row that holds laser pixels, ascending y; ``[]`` when no
+    contour survives the area filter."""
 
     def __init__(self, hsv_lower=None, hsv_upper=None, brightness_threshold=100, min_area=50, device: int = 0,
                  verbose: bool = False):
@@ -21,9 +24,73 @@ class SimpleLaserExtractor:
         self.min_area = min_area
         self.device = device
         self.verbose = verbose
+        self._h = None
+        self._cap = (0, 0)
+        if verbose:
+            print(f"SimpleLaserExtractor: HSV {self.hsv_lower} ~ {self.hsv_upper}, threshold {brightness_threshold}, "
+                  f"min area {min_area}")
+
+    def _release(self):
+        if self._h is not None:
+            N.lib.l3d_simple_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _handle(self, w, h):
+        mw, mh = self._cap
+        if self._h is None or w > mw or h > mh:
+            self._release()
+            self._cap = (max(w, mw), max(h, mh))
+            hd = C.c_void_p()
+            N.check(N.lib.l3d_simple_create(self._cap[0], self._cap[1], self.device, C.byref(hd)), "l3d_simple_create")
+            self._h = hd
+        return self._h
+
+    def _range(self):
+        lo = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_lower).reshape(3)])
+        hi = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_upper).reshape(3)])
+        return lo, hi
+
+    def extract_points(self, image: np.ndarray, want_masks: bool = False):
+        """(N,2) float64 array of (x, y); with want_masks also the three stage masks (3,H,W) uint8."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("SimpleLaserExtractor expects a BGR uint8 image of shape (H, W, 3)")
+        h, w = img.shape[:2]
+        hd = self._handle(w, h)
+        lo, hi = self._range()
+        xy = np.empty((h, 2), np.float64)
+        n = C.c_int(0)
+        masks = np.empty((3, h, w), np.uint8) if want_masks else None
+        N.check(N.lib.l3d_simple_extract(hd, N.ptr(img), w, h, lo, hi, int(self.brightness_threshold),
+                                         C.c_double(float(self.min_area)), N.ptr(xy), C.byref(n),
+                                         N.ptr(masks) if want_masks else None), "l3d_simple_extract")
+        pts = xy[: n.value].copy()
+        return (pts, masks) if want_masks else pts
 
     def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
-        raise NotImplementedError("SimpleLaserExtractor GPU path is not built yet")
+        return [(float(x), float(y)) for x, y in self.extract_points(image)]
+
+    def extract_device(self, image):
+        """torch uint8 CUDA tensor (H,W,3) -> list of (x, y); runs on torch's current stream."""
+        import torch
+
+        assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous() and image.dim() == 3
+        h, w = image.shape[:2]
+        hd = self._handle(w, h)
+        lo, hi = self._range()
+        xy = np.empty((h, 2), np.float64)
+        n = C.c_int(0)
+        stream = C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)
+        N.check(N.lib.l3d_simple_extract_device(hd, C.c_void_p(image.data_ptr()), w, h, lo, hi,
+                                                int(self.brightness_threshold), C.c_double(float(self.min_area)),
+                                                N.ptr(xy), C.byref(n), stream), "l3d_simple_extract_device")
+        return [(float(x), float(y)) for x, y in xy[: n.value]]
 
 
 class FastStegerExtractor:

@@ -10,7 +10,7 @@
 //                                 mirrored in x so that increasing disparity = increasing address
 //   Cvol   [B][H][W1][D]  s16     block-aggregated matching cost of the stripe that owns the row
 //   Tvol   [B][H][W1][D]  s16     top->down path cost
-//   Lvol   [B][H][W1][D]  s16     left->right path cost, overwritten by nothing else
+//   ckpt   [B][H][ceil(W1/4)][D] s16  left->right path state at every segment start (checkpoints)
 //   wta    [B][H][W1]     u32     (biased min S << 16 | argmin) or 0xFFFFFFFF (uniqueness reject)
 //   dsub   [B][H][W1]     s16     sub-pixel disparity (x16) of the column
 //   raw    [B][H][W]      s16     disparity after the left-right check
@@ -192,6 +192,13 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
     return pku_min(c0, c1);
 }
 
+// Inputs of one image row for the (up to 3) tile columns a DPP row computes pixel costs for.
+template <int NP>
+struct RowInputs {
+    uint2 lr[3];
+    uint8_t q[3][6][2 * NP];
+};
+
 template <int NP>
 __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol)
@@ -205,7 +212,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int own0 = n * g.stripe_sz;
     if (start >= end) return;
     const int NR = 2 * SH2 + 2;
-    const int tileC = 16 + 2 * SW2;
+    const int tileC = 16 + 2 * SW2;           // <= 36 (blockSize <= 21): at most 3 tile columns per DPP row
     uint32_t *pixT = smem;                    // [tileC][16][NP]
     uint32_t *ring = smem + tileC * 16 * NP;  // [NR][256][NP], thread-private slots
     const int xa = blockIdx.x * 16;
@@ -216,33 +223,51 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const uint8_t *rrev_b = rrev + (size_t)b * 6 * plane;
     const uint32_t P1v = pk_splat(min(g.P1, 32767));
 
+    // image column of each tile column this DPP row is responsible for (replicated at the cost-range border)
+    int xin[3];
+#pragma unroll
+    for (int ps = 0; ps < 3; ps++) {
+        int xc = xa - SW2 + grp + 16 * ps;
+        xc = xc < 0 ? 0 : (xc > W1 - 1 ? W1 - 1 : xc);
+        xin[ps] = xc + g.minX1;
+    }
+
     uint32_t Cst[NP], Tst[NP], hs[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = 0; }
     int topMin = 0;
 
-    // horizontal box sum of the pixel costs of image row k for this thread's column / disparities
-    auto compute_hs = [&](int k) {
+    auto load_row = [&](int k, RowInputs<NP> &in) {
+#pragma unroll
+        for (int ps = 0; ps < 3; ps++) {
+            if (grp + 16 * ps < tileC) {
+                const int x = xin[ps];
+                in.lr[ps] = lrec_b[(size_t)k * W + x];
+                const uint8_t *rp = rrev_b + (size_t)k * W + (W - 1 - x + g.minD + l * 2 * NP);
+#pragma unroll
+                for (int j = 0; j < 6; j++) load_bytes<NP>(rp + j * plane, in.q[ps][j]);
+            }
+        }
+    };
+    // pixel costs of the loaded row -> LDS tile -> horizontal box sum for this thread's column
+    auto box_row = [&](int k, const RowInputs<NP> &in) {
         __syncthreads();
-        for (int c = grp; c < tileC; c += 16) {
-            int xc = xa - SW2 + c;
-            xc = xc < 0 ? 0 : (xc > W1 - 1 ? W1 - 1 : xc);
-            const int x = xc + g.minX1;
-            const uint2 lr = lrec_b[(size_t)k * W + x];
-            const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
-            const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
-            const uint8_t *rp = rrev_b + (size_t)k * W + (W - 1 - x + g.minD + l * 2 * NP);
-            uint8_t q[6][2 * NP];
 #pragma unroll
-            for (int j = 0; j < 6; j++) load_bytes<NP>(rp + j * plane, q[j]);
+        for (int ps = 0; ps < 3; ps++) {
+            const int c = grp + 16 * ps;
+            if (c < tileC) {
+                const uint2 lr = in.lr[ps];
+                const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
+                const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
-                uint32_t v[6];
+                for (int p = 0; p < NP; p++) {
+                    uint32_t v[6];
 #pragma unroll
-                for (int j = 0; j < 6; j++) v[j] = (uint32_t)q[j][2 * p] | ((uint32_t)q[j][2 * p + 1] << 16);
-                const uint32_t cg = bt_pair(u, u0, u1, v[0], v[1], v[2]);
-                const uint32_t ci = bt_pair(t, t0, t1, v[3], v[4], v[5]);
-                pixT[(c * 16 + l) * NP + p] = cg + ((ci >> 2) & 0x3fff3fffu);
+                    for (int j = 0; j < 6; j++) v[j] = (uint32_t)in.q[ps][j][2 * p] | ((uint32_t)in.q[ps][j][2 * p + 1] << 16);
+                    const uint32_t cg = bt_pair(u, u0, u1, v[0], v[1], v[2]);
+                    const uint32_t ci = bt_pair(t, t0, t1, v[3], v[4], v[5]);
+                    pixT[(c * 16 + l) * NP + p] = cg + ((ci >> 2) & 0x3fff3fffu);
+                }
             }
         }
         __syncthreads();
@@ -256,10 +281,12 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         for (int p = 0; p < NP; p++) ring[((k % NR) * 256 + tid) * NP + p] = hs[p];
     };
 
+    RowInputs<NP> cur, nxt;
     // cost of the stripe's first row: rows above it replicate that row
     for (int k = start; k <= start + SH2; k++) {
         const int kk = min(k, H - 1);
-        compute_hs(kk);
+        load_row(kk, cur);
+        box_row(kk, cur);
         const int scale = (k == start) ? SH2 + 1 : 1;
 #pragma unroll
         for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pk_mul(hs[p], scale));
@@ -267,7 +294,11 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 
     uint32_t *Cout = Cvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
     uint32_t *Tout = Tvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
+    // row y needs image row y + 1 + SH2 for the step to y + 1: its inputs are fetched one iteration ahead
+    if (start + 1 < end && start + 1 + SH2 <= H - 1) load_row(start + 1 + SH2, cur);
     for (int y = start; y < end; y++) {
+        const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
+        if (fetch_next) load_row(y + 2 + SH2, nxt);
         topMin = sgm_step<NP>(Cst, Tst, topMin, P1v, g.P2);
         if (y >= own0 && active) {
             Pack<NP> pc, pt;
@@ -280,7 +311,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         if (y + 1 < end) {
             const int kadd = y + 1 + SH2;
             if (kadd <= H - 1) {
-                compute_hs(kadd);
+                box_row(kadd, cur);
             } else {
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = ring[(((H - 1) % NR) * 256 + tid) * NP + p];
@@ -292,110 +323,169 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
                 Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub);
             }
         }
+        if (fetch_next) cur = nxt;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: left->right pass (writes Lvol), then right->left pass + sum + WTA / uniqueness / sub-pixel.
+// K3: left->right and right->left paths, sum of the three paths, WTA / uniqueness / sub-pixel.
 // One DPP row (16 lanes) per image row; a 64-thread block covers 4 consecutive rows.
+// The left->right costs are needed in right->left order.  Instead of spilling them to HBM the
+// first sweep stores only its state every SEG columns (checkpoints); the second sweep walks the
+// segments right to left, re-runs the left->right recurrence inside the segment from its
+// checkpoint into registers, then runs the right->left recurrence over the same columns.  All
+// loads are issued one segment ahead of their use.
 // ---------------------------------------------------------------------------------------------
 template <int NP>
+struct SegLen {
+    static constexpr int value = NP <= 2 ? 8 : 4;
+};
+
+// winner-take-all, uniqueness test and parabola fit for one column from the summed costs S
+template <int NP>
+__device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, int grp, size_t col, uint32_t *__restrict__ wta,
+                                           int16_t *__restrict__ dsub)
+{
+    uint32_t key = 0xffffffffu;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const v2s s2 = as_v2s(S[p]);
+        const uint32_t k0 = ((uint32_t)((int)s2.x + 32768) << 16) | (uint32_t)(d0 + 2 * p);
+        const uint32_t k1 = ((uint32_t)((int)s2.y + 32768) << 16) | (uint32_t)(d0 + 2 * p + 1);
+        key = min(key, min(k0, k1));
+    }
+    key = row_min_u32(key);
+    const int best = (int)(key & 0xffffu);
+    const int minS = (int)(key >> 16) - 32768;
+    bool reject = false;
+    if (g.uniq > 0) {
+        bool bad = false;
+        const int lim = minS * 100, f = 100 - g.uniq;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const v2s s2 = as_v2s(S[p]);
+            const int da = d0 + 2 * p, db = da + 1;
+            bad |= ((int)s2.x * f < lim) && (abs(da - best) > 1);
+            bad |= ((int)s2.y * f < lim) && (abs(db - best) > 1);
+        }
+        const unsigned long long bal = __ballot(bad);
+        reject = ((bal >> (grp * 16)) & 0xffffull) != 0;
+    }
+    // S shifted by one disparity in both directions, for the parabola fit on the owning lane
+    const uint32_t below = dpp_row<DPP_ROW_SHR1>(0u, S[NP - 1]);
+    const uint32_t above = dpp_row<DPP_ROW_SHL1>(0u, S[0]);
+    if (best >= d0 && best < d0 + 2 * NP) {
+        uint32_t out_w = 0xffffffffu;
+        int dval = 0;
+        if (!reject) {
+            int sc = 0, sm = 0, sp = 0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t lo_src = (p > 0) ? S[p - 1] : below;
+                const uint32_t hi_src = (p < NP - 1) ? S[p + 1] : above;
+                const v2s cur = as_v2s(S[p]);
+                const v2s dm1 = as_v2s(__builtin_amdgcn_alignbit(S[p], lo_src, 16));
+                const v2s dp1 = as_v2s(__builtin_amdgcn_alignbit(hi_src, S[p], 16));
+                if (best == d0 + 2 * p) { sc = cur.x; sm = dm1.x; sp = dp1.x; }
+                if (best == d0 + 2 * p + 1) { sc = cur.y; sm = dm1.y; sp = dp1.y; }
+            }
+            int dd;
+            if (0 < best && best < g.D - 1) {
+                const int denom2 = max(sm + sp - 2 * sc, 1);
+                dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+            } else
+                dd = best * 16;
+            dval = dd + g.minD * 16;
+            out_w = key;
+        }
+        wta[col] = out_w;
+        dsub[col] = (int16_t)dval;
+    }
+}
+
+template <int NP>
 __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
-                                                   const uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Lvol,
+                                                   const uint32_t *__restrict__ Tvol, uint32_t *__restrict__ ckpt,
                                                    uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
 {
+    constexpr int SEG = SegLen<NP>::value;
     const int tid = threadIdx.x, grp = tid >> 4, l = tid & 15;
     const int row = blockIdx.x * 4 + grp;
     if (row >= nrows_total) return;
     const int W1 = g.W1;
+    const int nseg = (W1 + SEG - 1) / SEG;
     const size_t rs = (size_t)(16 * NP);            // u32 per column
     const size_t base = (size_t)row * W1 * rs + l * NP;
     const uint32_t *Cp = Cvol + base;
     const uint32_t *Tp = Tvol + base;
-    uint32_t *Lp = Lvol + base;
+    uint32_t *ck = ckpt + (size_t)row * nseg * rs + l * NP;
     const uint32_t P1v = pk_splat(min(g.P1, 32767));
+    const int d0 = l * 2 * NP; // first disparity index held by this lane
+    auto ldC = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Cp + (size_t)min(max(x, 0), W1 - 1) * rs); };
+    auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tp + (size_t)min(max(x, 0), W1 - 1) * rs); };
 
+    // ---- sweep 1: left -> right, keep the state at every segment start ----
     uint32_t st[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = 0;
     int mn = 0;
-#pragma unroll 4
-    for (int xc = 0; xc < W1; xc++) {
-        const Pack<NP> c = *reinterpret_cast<const Pack<NP> *>(Cp + xc * rs);
-        mn = sgm_step<NP>(c.v, st, mn, P1v, g.P2);
+    Pack<NP> cb[SEG], nb[SEG];
+#pragma unroll
+    for (int u = 0; u < SEG; u++) cb[u] = ldC(u);
+    for (int j = 0; j < nseg; j++) {
         Pack<NP> o;
 #pragma unroll
         for (int p = 0; p < NP; p++) o.v[p] = st[p];
-        *reinterpret_cast<Pack<NP> *>(Lp + xc * rs) = o;
+        *reinterpret_cast<Pack<NP> *>(ck + (size_t)j * rs) = o;
+#pragma unroll
+        for (int u = 0; u < SEG; u++) nb[u] = ldC((j + 1) * SEG + u);
+#pragma unroll
+        for (int u = 0; u < SEG; u++)
+            if (j * SEG + u < W1) mn = sgm_step<NP>(cb[u].v, st, mn, P1v, g.P2);
+#pragma unroll
+        for (int u = 0; u < SEG; u++) cb[u] = nb[u];
     }
 
+    // ---- sweep 2: segments right -> left ----
+    uint32_t rst[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) st[p] = 0;
-    mn = 0;
-    const int d0 = l * 2 * NP; // first disparity index held by this lane
-#pragma unroll 2
-    for (int xc = W1 - 1; xc >= 0; xc--) {
-        const Pack<NP> c = *reinterpret_cast<const Pack<NP> *>(Cp + xc * rs);
-        const Pack<NP> lf = *reinterpret_cast<const Pack<NP> *>(Lp + xc * rs);
-        const Pack<NP> tp = *reinterpret_cast<const Pack<NP> *>(Tp + xc * rs);
-        mn = sgm_step<NP>(c.v, st, mn, P1v, g.P2);
-        uint32_t S[NP];
-        uint32_t key = 0xffffffffu;
+    for (int p = 0; p < NP; p++) rst[p] = 0;
+    int rmn = 0;
+    Pack<NP> tb[SEG], ntb[SEG], fs, nfs;
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            S[p] = pk_adds(pk_adds(st[p], lf.v[p]), tp.v[p]);
-            const v2s s2 = as_v2s(S[p]);
-            const uint32_t k0 = ((uint32_t)((int)s2.x + 32768) << 16) | (uint32_t)(d0 + 2 * p);
-            const uint32_t k1 = ((uint32_t)((int)s2.y + 32768) << 16) | (uint32_t)(d0 + 2 * p + 1);
-            key = min(key, min(k0, k1));
+    for (int u = 0; u < SEG; u++) { cb[u] = ldC((nseg - 1) * SEG + u); tb[u] = ldT((nseg - 1) * SEG + u); }
+    fs = *reinterpret_cast<const Pack<NP> *>(ck + (size_t)(nseg - 1) * rs);
+    for (int j = nseg - 1; j >= 0; j--) {
+        const int jn = max(j - 1, 0);
+#pragma unroll
+        for (int u = 0; u < SEG; u++) { nb[u] = ldC(jn * SEG + u); ntb[u] = ldT(jn * SEG + u); }
+        nfs = *reinterpret_cast<const Pack<NP> *>(ck + (size_t)jn * rs);
+        // left -> right costs of this segment, recomputed from the checkpoint
+        uint32_t fst[NP], mv = 0x7fff7fffu;
+#pragma unroll
+        for (int p = 0; p < NP; p++) { fst[p] = fs.v[p]; mv = pk_min(mv, fst[p]); }
+        int fmn = row_min_pk(mv); // the previous minimum is the minimum of the previous state
+        uint32_t Lseg[SEG][NP];
+#pragma unroll
+        for (int u = 0; u < SEG; u++) {
+            if (j * SEG + u < W1) fmn = sgm_step<NP>(cb[u].v, fst, fmn, P1v, g.P2);
+#pragma unroll
+            for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
-        key = row_min_u32(key);
-        const int best = (int)(key & 0xffffu);
-        const int minS = (int)(key >> 16) - 32768;
-        bool reject = false;
-        if (g.uniq > 0) {
-            bool bad = false;
-            const int lim = minS * 100, f = 100 - g.uniq;
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const v2s s2 = as_v2s(S[p]);
-                const int da = d0 + 2 * p, db = da + 1;
-                bad |= ((int)s2.x * f < lim) && (abs(da - best) > 1);
-                bad |= ((int)s2.y * f < lim) && (abs(db - best) > 1);
+        for (int u = SEG - 1; u >= 0; u--) {
+            const int xc = j * SEG + u;
+            if (xc < W1) {
+                rmn = sgm_step<NP>(cb[u].v, rst, rmn, P1v, g.P2);
+                uint32_t S[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) S[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tb[u].v[p]);
+                wta_column<NP>(g, S, d0, grp, (size_t)row * W1 + xc, wta, dsub);
             }
-            const unsigned long long bal = __ballot(bad);
-            reject = ((bal >> (grp * 16)) & 0xffffull) != 0;
         }
-        // S shifted by one disparity in both directions, for the parabola fit on the owning lane
-        const uint32_t below = dpp_row<DPP_ROW_SHR1>(0u, S[NP - 1]);
-        const uint32_t above = dpp_row<DPP_ROW_SHL1>(0u, S[0]);
-        if (best >= d0 && best < d0 + 2 * NP) {
-            uint32_t out_w = 0xffffffffu;
-            int dval = 0;
-            if (!reject) {
-                int sc = 0, sm = 0, sp = 0;
 #pragma unroll
-                for (int p = 0; p < NP; p++) {
-                    const uint32_t lo_src = (p > 0) ? S[p - 1] : below;
-                    const uint32_t hi_src = (p < NP - 1) ? S[p + 1] : above;
-                    const v2s cur = as_v2s(S[p]);
-                    const v2s dm1 = as_v2s(__builtin_amdgcn_alignbit(S[p], lo_src, 16));
-                    const v2s dp1 = as_v2s(__builtin_amdgcn_alignbit(hi_src, S[p], 16));
-                    if (best == d0 + 2 * p) { sc = cur.x; sm = dm1.x; sp = dp1.x; }
-                    if (best == d0 + 2 * p + 1) { sc = cur.y; sm = dm1.y; sp = dp1.y; }
-                }
-                int dd;
-                if (0 < best && best < g.D - 1) {
-                    const int denom2 = max(sm + sp - 2 * sc, 1);
-                    dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-                } else
-                    dd = best * 16;
-                dval = dd + g.minD * 16;
-                out_w = key;
-            }
-            wta[(size_t)row * W1 + xc] = out_w;
-            dsub[(size_t)row * W1 + xc] = (int16_t)dval;
-        }
+        for (int u = 0; u < SEG; u++) { cb[u] = nb[u]; tb[u] = ntb[u]; }
+        fs = nfs;
     }
 }
 
@@ -771,7 +861,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     alloc((void **)&h->rrev, B * px * 6 + 64);
     alloc((void **)&h->Cvol, vol);
     alloc((void **)&h->Tvol, vol);
-    alloc((void **)&h->Lvol, vol);
+    alloc((void **)&h->Lvol, g.W1 > 0 ? B * height * (size_t)cdiv(g.W1, 4) * g.D * sizeof(int16_t) : 0);
     alloc((void **)&h->wta, cols * 4);
     alloc((void **)&h->dsub, cols * 2);
     alloc((void **)&h->raw, B * px * 2);

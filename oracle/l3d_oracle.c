@@ -973,3 +973,176 @@ ORC_API int orc_reconstruct_plane(const double *uv, int n, const double *Kinv, c
 }
 
 ORC_API const char *orc_version(void) { return "l3d-oracle 0.1"; }
+
+/* ------------------------------------------------------------------------ */
+/* H0..H4  SimpleLaserExtractor.extract_centerline                            */
+/* core/laser_extractor.py:45-100                                             */
+/*   cv2.cvtColor(BGR2HSV) + inRange, cv2.cvtColor(BGR2GRAY) + threshold,     */
+/*   bitwise_and, morphologyEx CLOSE then OPEN with a 3x3 rectangle,          */
+/*   findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), contourArea > min_area,*/
+/*   drawContours(filled), per-row intensity-weighted centroid.               */
+/* Restated sequentially, the way OpenCV does it: Suzuki-Abe border following */
+/* of each top-level 8-connected component from its raster-first pixel,       */
+/* shoelace area of the traced chain, even-odd scanline fill of the chain     */
+/* polygon plus the chain pixels themselves.                                  */
+/* ------------------------------------------------------------------------ */
+static void morph3x3(const uint8_t *src, int W, int H, int dilate, uint8_t *dst)
+{
+    /* pixels outside the image never win (erode: +inf, dilate: -inf) */
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int acc = dilate ? 0 : 255;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    int v = src[(size_t)yy * W + xx];
+                    acc = dilate ? imax(acc, v) : imin(acc, v);
+                }
+            dst[(size_t)y * W + x] = (uint8_t)acc;
+        }
+}
+
+/* dbg (optional): 3 planes W*H: combined mask, mask after morphology, final filled mask */
+ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_stride, const int *lower, const int *upper,
+                               int brightness_threshold, double min_area, double *xy, int *count, uint8_t *dbg)
+{
+    hsv_tables();
+    const size_t n = (size_t)W * H;
+    uint8_t *gray = (uint8_t *)malloc(n), *m0 = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n), *fin = (uint8_t *)calloc(n, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t *px = bgr + (ptrdiff_t)y * row_stride + 3 * x;
+            int hh, ss, vv;
+            bgr2hsv_px(px[0], px[1], px[2], &hh, &ss, &vv);
+            int g = (px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15;
+            gray[(size_t)y * W + x] = (uint8_t)g;
+            int in = hh >= lower[0] && hh <= upper[0] && ss >= lower[1] && ss <= upper[1] && vv >= lower[2] && vv <= upper[2];
+            m0[(size_t)y * W + x] = (in && g > brightness_threshold) ? 255 : 0;
+        }
+    if (dbg) memcpy(dbg, m0, n);
+    morph3x3(m0, W, H, 1, m1); morph3x3(m1, W, H, 0, m0);   /* close = erode(dilate) */
+    morph3x3(m0, W, H, 0, m1); morph3x3(m1, W, H, 1, m0);   /* open  = dilate(erode) */
+    if (dbg) memcpy(dbg + n, m0, n);
+
+    /* padded binary image, 1-pixel zero frame */
+    const int PW = W + 2, PH = H + 2;
+    uint8_t *f = (uint8_t *)calloc((size_t)PW * PH, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) f[(size_t)(y + 1) * PW + x + 1] = m0[(size_t)y * W + x] ? 1 : 0;
+    int *comp = (int *)calloc((size_t)PW * PH, sizeof(int));     /* 8-connected foreground labels, 1.. */
+    uint8_t *outer = (uint8_t *)calloc((size_t)PW * PH, 1);      /* background 4-connected to the frame */
+    int *stack = (int *)malloc((size_t)PW * PH * sizeof(int));
+    /* outer background */
+    {
+        int sp = 0;
+        stack[sp++] = 0; outer[0] = 1;
+        while (sp) {
+            int q = stack[--sp], qy = q / PW, qx = q % PW;
+            const int dy4[4] = {0, 0, 1, -1}, dx4[4] = {1, -1, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                int yy = qy + dy4[k], xx = qx + dx4[k];
+                if (yy < 0 || yy >= PH || xx < 0 || xx >= PW) continue;
+                int t = yy * PW + xx;
+                if (!f[t] && !outer[t]) { outer[t] = 1; stack[sp++] = t; }
+            }
+        }
+    }
+    /* direction table, counter-clockwise on screen: E, NE, N, NW, W, SW, S, SE (dy, dx) */
+    static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1}, DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    int ncomp = 0;
+    int *chain = (int *)malloc((size_t)PW * PH * 4 * sizeof(int)); /* a border pixel is visited at most 4 times */
+    double *cross_x = (double *)malloc(((size_t)PW + 4) * sizeof(double));
+    for (int i = 1; i <= H; i++)
+        for (int j = 1; j <= W; j++) {
+            int s = i * PW + j;
+            if (!f[s] || comp[s]) continue;
+            /* new component: flood fill (8-connectivity), note whether it touches the outer background */
+            ncomp++;
+            int sp = 0, top_level = 0;
+            stack[sp++] = s; comp[s] = ncomp;
+            while (sp) {
+                int q = stack[--sp], qy = q / PW, qx = q % PW;
+                for (int k = 0; k < 8; k++) {
+                    int t = (qy + DY[k]) * PW + qx + DX[k];
+                    if (f[t] && !comp[t]) { comp[t] = ncomp; stack[sp++] = t; }
+                    if ((k & 1) == 0 && !f[t] && outer[t]) top_level = 1;
+                }
+            }
+            if (!top_level) continue; /* lies inside a hole of another component: not an external contour */
+            /* Suzuki-Abe border following from the raster-first pixel (i, j); its west neighbour is background */
+            int nchain = 0;
+            int i1 = -1, j1 = -1;
+            for (int k = 0; k < 8; k++) { /* clockwise from W: W, NW, N, NE, E, SE, S, SW */
+                int dir = (4 - k + 8) & 7;
+                if (f[(i + DY[dir]) * PW + j + DX[dir]]) { i1 = i + DY[dir]; j1 = j + DX[dir]; break; }
+            }
+            chain[nchain++] = s;
+            if (i1 >= 0) {
+                int i2 = i1, j2 = j1, i3 = i, j3 = j;
+                for (;;) {
+                    /* direction of (i2,j2) seen from (i3,j3) */
+                    int d2 = 0;
+                    for (int k = 0; k < 8; k++)
+                        if (i3 + DY[k] == i2 && j3 + DX[k] == j2) d2 = k;
+                    int i4 = -1, j4 = -1;
+                    for (int k = 1; k <= 8; k++) { /* counter-clockwise, starting after (i2,j2) */
+                        int dir = (d2 + k) & 7;
+                        if (f[(i3 + DY[dir]) * PW + j3 + DX[dir]]) { i4 = i3 + DY[dir]; j4 = j3 + DX[dir]; break; }
+                    }
+                    if (i4 == i && j4 == j && i3 == i1 && j3 == j1) break;
+                    i2 = i3; j2 = j3; i3 = i4; j3 = j4;
+                    chain[nchain++] = i3 * PW + j3;
+                }
+            }
+            /* cv2.contourArea: |sum(prev.x * p.y - prev.y * p.x)| / 2 */
+            double a00 = 0;
+            {
+                int prev = chain[nchain - 1];
+                for (int k = 0; k < nchain; k++) {
+                    int p = chain[k];
+                    double px_ = prev % PW, py_ = prev / PW, qx = p % PW, qy = p / PW;
+                    a00 += px_ * qy - py_ * qx;
+                    prev = p;
+                }
+            }
+            if (!(fabs(a00 * 0.5) > min_area)) continue;
+            /* cv2.drawContours(..., thickness=-1): chain pixels + even-odd interior */
+            int ymin = PH, ymax = -1;
+            for (int k = 0; k < nchain; k++) {
+                int p = chain[k];
+                fin[(size_t)(p / PW - 1) * W + (p % PW - 1)] = 255;
+                ymin = imin(ymin, p / PW); ymax = imax(ymax, p / PW);
+            }
+            for (int y = ymin; y <= ymax; y++) {
+                int nc = 0;
+                for (int k = 0; k < nchain; k++) {
+                    int a = chain[k], b = chain[(k + 1) % nchain];
+                    int y1 = a / PW, y2 = b / PW;
+                    if ((y1 <= y) == (y2 <= y)) continue;
+                    cross_x[nc++] = (y1 < y2) ? (double)(a % PW) : (double)(b % PW); /* x at the endpoint on row y */
+                    if (nc >= PW + 4) { /* grow */
+                        cross_x = (double *)realloc(cross_x, (size_t)(nc + PW + 4) * 2 * sizeof(double));
+                    }
+                }
+                for (int x = 1; x <= W; x++) {
+                    int c = 0;
+                    for (int k = 0; k < nc; k++) c += cross_x[k] > x;
+                    if (c & 1) fin[(size_t)(y - 1) * W + (x - 1)] = 255;
+                }
+            }
+        }
+    if (dbg) memcpy(dbg + 2 * n, fin, n);
+    /* per-row intensity-weighted centroid */
+    int m = 0;
+    for (int y = 0; y < H; y++) {
+        double sxw = 0, sw = 0;
+        int any = 0;
+        for (int x = 0; x < W; x++)
+            if (fin[(size_t)y * W + x]) { any = 1; sxw += (double)x * gray[(size_t)y * W + x]; sw += gray[(size_t)y * W + x]; }
+        if (any && sw > 0) { xy[2 * m] = sxw / sw; xy[2 * m + 1] = (double)y; m++; }
+    }
+    *count = m;
+    free(gray); free(m0); free(m1); free(fin); free(f); free(comp); free(outer); free(stack); free(chain); free(cross_x);
+    return 0;
+}

@@ -279,3 +279,22 @@ def reconstruct_plane(uv, K, plane, refraction=True, n_water=1.33) -> np.ndarray
     lib().orc_reconstruct_plane(_p(uv, C.c_double), len(uv), _p(kinv, C.c_double), _p(plane, C.c_double),
                                 int(bool(refraction)), C.c_double(n_water), _p(out, C.c_double))
     return out
+
+
+def simple_extract(bgr: np.ndarray, hsv_lower=(40, 50, 100), hsv_upper=(80, 255, 255), brightness_threshold=100,
+                   min_area=50, want_masks=False):
+    """SimpleLaserExtractor.extract_centerline: (N,2) float64 array of (x, y), one row per image row."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    lo = (C.c_int * 3)(*[int(v) for v in hsv_lower])
+    hi = (C.c_int * 3)(*[int(v) for v in hsv_upper])
+    xy = np.empty((h, 2), np.float64)
+    n = C.c_int(0)
+    masks = np.zeros((3, h, w), np.uint8) if want_masks else None
+    rc = lib().orc_simple_extract(_p(bgr, C.c_uint8), w, h, C.c_ssize_t(3 * w), lo, hi, int(brightness_threshold),
+                                  C.c_double(float(min_area)), _p(xy, C.c_double), C.byref(n),
+                                  _p(masks, C.c_uint8) if want_masks else None)
+    if rc:
+        raise RuntimeError("orc_simple_extract failed")
+    pts = xy[: n.value].copy()
+    return (pts, masks) if want_masks else pts
