@@ -64,13 +64,16 @@ def laser_centre(width: int, height: int) -> np.ndarray:
 
 
 def add_laser(bgr: np.ndarray, s: float = 2.0) -> np.ndarray:
-    """Saturating add of a green Gaussian ridge (B,G,R amplitude 60,255,60)."""
+    """Blends a green ridge into the frame: flat-topped Gaussian profile (about 4 px at full
+    strength) towards B,G,R = (140, 255, 140).  That colour has gray 208 (> the extractors'
+    brightness threshold 200, which the texture, capped at 180, never reaches) and HSV
+    (60, 115, 255), inside Config's SIMPLE_LASER_HSV range."""
     h, w, _ = bgr.shape
     xc = laser_centre(w, h)[:, None]
-    prof = np.exp(-0.5 * ((np.arange(w)[None, :] - xc) / s) ** 2)
+    prof = np.minimum(1.0, 1.6 * np.exp(-0.5 * ((np.arange(w)[None, :] - xc) / s) ** 2))
     out = bgr.astype(np.float64)
-    for c, amp in enumerate((60.0, 255.0, 60.0)):
-        out[:, :, c] += amp * prof
+    for c, target in enumerate((140.0, 255.0, 140.0)):
+        out[:, :, c] += (target - out[:, :, c]) * prof
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 

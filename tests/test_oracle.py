@@ -170,3 +170,75 @@ def test_steger_roi_offsets_and_empty(O):
     key = np.floor(full[:, 1] + 0.5) * 10000 + full[:, 0]
     rows = np.rint(full[:, 1])
     assert (np.diff(rows) >= -1).all()
+
+
+def _blob_image(rng, H, W, with_rings=True):
+    """BGR image whose green/bright pixels form random blobs (plus diagonal squares and a ring with an island)."""
+    from scipy import ndimage as ndi
+
+    z = ndi.gaussian_filter(rng.normal(size=(H, W)), rng.uniform(0.8, 2.5))
+    m = z > rng.uniform(-0.2, 0.6) * z.std()
+    if with_rings and H > 24 and W > 24:
+        for _ in range(4):
+            y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+            m[y:y + 3, x:x + 3] = True
+            m[y + 3:y + 6, x + 3:x + 6] = True
+        y, x = rng.integers(0, H - 12), rng.integers(0, W - 12)
+        m[y:y + 11, x:x + 11] = True
+        m[y + 3:y + 8, x + 3:x + 8] = False
+        m[y + 4:y + 7, x + 4:x + 7] = True
+    img = np.zeros((H, W, 3), np.uint8)
+    img[...] = (30, 40, 30)
+    img[m] = (140, 255, 140)      # gray 208 > 200, HSV (60, 115, 255): inside Config's green range
+    img[..., 1] = np.where(m, rng.integers(245, 256, (H, W)), img[..., 1])
+    return img
+
+
+def test_simple_extractor_known_answers(O):
+    cfg = dict(hsv_lower=(50, 100, 180), hsv_upper=(70, 255, 255), brightness_threshold=200, min_area=50)
+    img = np.zeros((60, 80, 3), np.uint8)
+    img[...] = (30, 40, 30)
+    img[10:40, 20:31] = (140, 255, 140)            # 30 x 11 block: contour area (29)(10) = 290
+    img[45:50, 50:55] = (140, 255, 140)            # 5 x 5 block: contour area 16 < 50 -> dropped
+    img[20:30, 24:27] = (30, 40, 30)             # a hole inside the big block: filled by drawContours
+    pts, masks = O.simple_extract(img, want_masks=True, **cfg)
+    assert masks[1][10:40, 20:31].sum() == 255 * (30 * 11 - 10 * 3)
+    assert (masks[2][10:40, 20:31] == 255).all() and masks[2].sum() == 255 * 30 * 11
+    assert len(pts) == 30 and np.array_equal(pts[:, 1], np.arange(10, 40))
+    g_on, g_off = int(O.bgr2gray(img)[10, 20]), int(O.bgr2gray(img)[20, 24])
+    xs = np.arange(20, 31)
+    w = np.where((xs >= 24) & (xs < 27), g_off, g_on).astype(float)
+    np.testing.assert_allclose(pts[5, 0], 25.0)                       # rows without the hole: symmetric
+    np.testing.assert_allclose(pts[15, 0], (xs * w).sum() / w.sum())  # hole rows: weighted by the darker gray
+    assert len(O.simple_extract(np.zeros((20, 20, 3), np.uint8), **cfg)) == 0
+    # a one-pixel-wide line has zero contour area and never passes the filter
+    line = np.zeros((40, 40, 3), np.uint8)
+    line[5:35, 20:23] = (140, 255, 140)
+    assert len(O.simple_extract(line, **dict(cfg, min_area=0))) == 30
+    line2 = np.zeros((40, 40, 3), np.uint8)
+    line2[5:35, 20] = (140, 255, 140)
+    assert len(O.simple_extract(line2, **dict(cfg, min_area=0))) == 0   # removed by the 3x3 opening
+
+
+def test_simple_extractor_fill_equals_unreachable_from_outside(O):
+    """Cross-check of the sequential border-following restatement against an independent formulation
+    (scipy labelling): filled external contours = what a 4-connected flood from outside cannot reach."""
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        H, W = int(rng.integers(30, 70)), int(rng.integers(30, 90))
+        img = _blob_image(rng, H, W)
+        pts, masks = O.simple_extract(img, (50, 100, 180), (70, 255, 255), 200, 0, want_masks=True)
+        f = np.zeros((H + 2, W + 2), bool)
+        f[1:-1, 1:-1] = masks[1] > 0
+        fg, nfg = ndi.label(f, structure=np.ones((3, 3)))
+        sizes = ndi.sum(f, fg, index=np.arange(1, nfg + 1))
+        lab, _ = ndi.label(~f, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        filled = lab != lab[0, 0]
+        # with min_area = 0 only degenerate (zero-area) contours are dropped: every kept pixel is in `filled`
+        fin = np.zeros_like(f)
+        fin[1:-1, 1:-1] = masks[2] > 0
+        assert not (fin & ~filled).any()
+        # and every component holding a 3x3 block has positive contour area, so it is kept
+        assert (fin[1:-1, 1:-1] >= (masks[1] > 0)).all()
