@@ -80,21 +80,34 @@ __device__ __forceinline__ uint32_t dpp_row(uint32_t fill, uint32_t src)
 // all-lanes minimum of a u32 over the 16 lanes of a DPP row
 __device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
 {
-    v = min(v, dpp_row<DPP_ROW_ROR8>(v, v));
-    v = min(v, dpp_row<DPP_ROW_ROR4>(v, v));
-    v = min(v, dpp_row<DPP_ROW_ROR2>(v, v));
-    v = min(v, dpp_row<DPP_ROW_ROR1>(v, v));
+    // a rotation has a source for every lane, so `fill` is never used; passing the identity of
+    // min lets the compiler fold each move into one v_min_u32_dpp
+    v = min(v, dpp_row<DPP_ROW_ROR8>(0xffffffffu, v));
+    v = min(v, dpp_row<DPP_ROW_ROR4>(0xffffffffu, v));
+    v = min(v, dpp_row<DPP_ROW_ROR2>(0xffffffffu, v));
+    v = min(v, dpp_row<DPP_ROW_ROR1>(0xffffffffu, v));
     return v;
 }
-// all-lanes minimum over both halves of a packed int16 pair across the row; returns the scalar
+// all-lanes minimum over both halves of a packed int16 pair across the row; returns the scalar.
+// The two halves are folded into one int first: packed 16-bit ops cannot carry a DPP modifier,
+// 32-bit v_min_i32 can.
 __device__ __forceinline__ int row_min_pk(uint32_t v)
 {
-    v = pk_min(v, dpp_row<DPP_ROW_ROR8>(v, v));
-    v = pk_min(v, dpp_row<DPP_ROW_ROR4>(v, v));
-    v = pk_min(v, dpp_row<DPP_ROW_ROR2>(v, v));
-    v = pk_min(v, dpp_row<DPP_ROW_ROR1>(v, v));
-    v2s p = as_v2s(v);
-    return min((int)p.x, (int)p.y);
+    const v2s p = as_v2s(v);
+    int m = min((int)p.x, (int)p.y);
+    m = min(m, (int)dpp_row<DPP_ROW_ROR8>(0x7fffffffu, (uint32_t)m));
+    m = min(m, (int)dpp_row<DPP_ROW_ROR4>(0x7fffffffu, (uint32_t)m));
+    m = min(m, (int)dpp_row<DPP_ROW_ROR2>(0x7fffffffu, (uint32_t)m));
+    m = min(m, (int)dpp_row<DPP_ROW_ROR1>(0x7fffffffu, (uint32_t)m));
+    return m;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store (vmcnt(0)), which would drain the row prefetch and expose
+// the latency of the volume stores at every row; the tiles exchanged here live in LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int NP>
@@ -251,7 +264,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     };
     // pixel costs of the loaded row -> LDS tile -> horizontal box sum for this thread's column
     auto box_row = [&](int k, const RowInputs<NP> &in) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int ps = 0; ps < 3; ps++) {
             const int c = grp + 16 * ps;
@@ -270,7 +283,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int p = 0; p < NP; p++) hs[p] = 0;
         for (int j = 0; j <= 2 * SW2; j++) {
