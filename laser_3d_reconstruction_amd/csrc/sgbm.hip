@@ -17,18 +17,20 @@
 //   med    [B][H][W]      s16     after the 3x3 median (speckle filter runs in place on the output)
 //   labels [B][H][W]      s32     union-find parents of the speckle filter; sizes, tsizes [B][H][W] s32
 //
-// Work decomposition: a disparity vector of one pixel lives in one DPP row (16 lanes); each lane
-// holds 2*NP consecutive disparities as NP packed int16 pairs (D = 32*NP), so the d-1 / d+1
-// neighbours of the SGM recurrence are one row_shr / row_shl DPP move plus v_alignbit, the
-// min over d is a 4-step row_ror butterfly, and all cost arithmetic is v_pk_*_i16 with the
-// clamp bit (the 16-bit saturating arithmetic the recurrence is defined in).  A 64-lane wave
-// therefore carries 4 independent pixels: 4 image columns in the vertical kernel, 4 image rows
-// in the horizontal kernel.
+// Work decomposition: a disparity vector of one pixel lives in a group of LPP lanes inside one
+// DPP row (LPP = 8 up to 64 disparities, else 16); each lane holds 2*NP consecutive disparities
+// as NP packed int16 pairs (D = 2*NP*LPP), so the d-1 / d+1 neighbours of the SGM recurrence are
+// one row_shr / row_shl DPP move plus v_alignbit, the min over d is a 3- or 4-step DPP butterfly,
+// and all cost arithmetic is v_pk_*_i16 with the clamp bit (the 16-bit saturating arithmetic the
+// recurrence is defined in).  A 64-lane wave therefore carries 64/LPP independent pixels: image
+// columns in the vertical kernel, image rows in the horizontal kernel.
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 namespace l3d {
@@ -41,7 +43,8 @@ struct SgbmGeom {
     int minX1, maxX1, W1, invalid16;
     int stripe_sz, stripe_overlap;
     int speckleWindowSize, speckleRange;
-    int NP; // packed pairs per lane, D = 32 * NP
+    int LPP; // lanes that share one pixel's disparity vector: 8 or 16
+    int NP;  // packed int16 pairs per lane, D = 2 * NP * LPP
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -70,36 +73,39 @@ __device__ __forceinline__ uint32_t dpp_row(uint32_t fill, uint32_t src)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)src, CTRL, 0xf, 0xf, false);
 }
-#define DPP_ROW_SHL1 0x101 // lane i <- lane i+1
-#define DPP_ROW_SHR1 0x111 // lane i <- lane i-1
-#define DPP_ROW_ROR1 0x121
-#define DPP_ROW_ROR2 0x122
-#define DPP_ROW_ROR4 0x124
-#define DPP_ROW_ROR8 0x128
+#define DPP_ROW_SHL1 0x101        // lane i <- lane i+1
+#define DPP_ROW_SHR1 0x111        // lane i <- lane i-1
+#define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]: lane i <- lane i^1
+#define DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]: lane i <- lane i^2
+#define DPP_ROW_HALF_MIRROR 0x141 // lane i <- lane 7-i inside each half row
+#define DPP_ROW_MIRROR 0x140      // lane i <- lane 15-i
 
-// all-lanes minimum of a u32 over the 16 lanes of a DPP row
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
+// A pixel's disparity vector is spread over a group of LPP consecutive lanes (LPP = 4, 8 or 16,
+// groups aligned inside a DPP row).  All-lanes minimum over one group; every move has a source
+// for every lane, so `fill` is never used: passing the identity of min lets the compiler fold
+// each move into one v_min_*_dpp.  After the two quad steps a quad is uniform, so the mirrored
+// moves deliver the other quad's / other half's value.
+template <int LPP>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
 {
-    // a rotation has a source for every lane, so `fill` is never used; passing the identity of
-    // min lets the compiler fold each move into one v_min_u32_dpp
-    v = min(v, dpp_row<DPP_ROW_ROR8>(0xffffffffu, v));
-    v = min(v, dpp_row<DPP_ROW_ROR4>(0xffffffffu, v));
-    v = min(v, dpp_row<DPP_ROW_ROR2>(0xffffffffu, v));
-    v = min(v, dpp_row<DPP_ROW_ROR1>(0xffffffffu, v));
+    v = min(v, dpp_row<DPP_QUAD_XOR1>(0xffffffffu, v));
+    v = min(v, dpp_row<DPP_QUAD_XOR2>(0xffffffffu, v));
+    if (LPP >= 8) v = min(v, dpp_row<DPP_ROW_HALF_MIRROR>(0xffffffffu, v));
+    if (LPP >= 16) v = min(v, dpp_row<DPP_ROW_MIRROR>(0xffffffffu, v));
     return v;
 }
-// all-lanes minimum over both halves of a packed int16 pair across the row; returns the scalar.
-// The two halves are folded into one int first: packed 16-bit ops cannot carry a DPP modifier,
-// 32-bit v_min_i32 can.
-__device__ __forceinline__ int row_min_pk(uint32_t v)
+// Minimum over both int16 halves of `v` and over the lanes of the group, returned in both
+// halves of the result.  A word with two equal halves orders as int32 exactly like its halves
+// order as int16, and 32-bit v_min_i32 can carry a DPP modifier (packed 16-bit ops cannot).
+template <int LPP>
+__device__ __forceinline__ uint32_t group_min_splat(uint32_t v)
 {
-    const v2s p = as_v2s(v);
-    int m = min((int)p.x, (int)p.y);
-    m = min(m, (int)dpp_row<DPP_ROW_ROR8>(0x7fffffffu, (uint32_t)m));
-    m = min(m, (int)dpp_row<DPP_ROW_ROR4>(0x7fffffffu, (uint32_t)m));
-    m = min(m, (int)dpp_row<DPP_ROW_ROR2>(0x7fffffffu, (uint32_t)m));
-    m = min(m, (int)dpp_row<DPP_ROW_ROR1>(0x7fffffffu, (uint32_t)m));
-    return m;
+    int m = (int)pk_min(v, __builtin_amdgcn_alignbit(v, v, 16));
+    m = min(m, (int)dpp_row<DPP_QUAD_XOR1>(0x7fffffffu, (uint32_t)m));
+    m = min(m, (int)dpp_row<DPP_QUAD_XOR2>(0x7fffffffu, (uint32_t)m));
+    if (LPP >= 8) m = min(m, (int)dpp_row<DPP_ROW_HALF_MIRROR>(0x7fffffffu, (uint32_t)m));
+    if (LPP >= 16) m = min(m, (int)dpp_row<DPP_ROW_MIRROR>(0x7fffffffu, (uint32_t)m));
+    return (uint32_t)m;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -111,22 +117,44 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 template <int NP>
-struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : 4))) Pack {
+struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : (NP % 2 == 0 ? 8 : 4)))) Pack {
     uint32_t v[NP];
 };
 
-// One step of the SGM recurrence on a disparity vector spread over a DPP row:
+// Penalties of the recurrence as packed int16 splats.  prevMin + P2 saturates at 32767 in the
+// recurrence; P2 itself may exceed 32767 (P2 = 96*blockSize^2 does from blockSize 19 on), so it
+// is applied as up to three saturating additions of non-negative parts, which equals
+// min(prevMin + P2, 32767) exactly for every int16 prevMin.
+struct SgmPenalty {
+    uint32_t P1v, P2a, P2b, P2c;
+};
+__device__ __forceinline__ SgmPenalty make_penalty(const SgbmGeom &g)
+{
+    SgmPenalty k;
+    k.P1v = pk_splat(min(g.P1, 32767));
+    const int a = min(g.P2, 32767), b = min(g.P2 - a, 32767), c = min(g.P2 - a - b, 32767);
+    k.P2a = pk_splat(a); k.P2b = pk_splat(b); k.P2c = pk_splat(c);
+    return k;
+}
+
+// One step of the SGM recurrence on a disparity vector spread over a lane group:
 //   out[d] = C[d] + min(prev[d], prev[d-1]+P1, prev[d+1]+P1, prevMin+P2) - (prevMin+P2)
-// in saturating int16 arithmetic.  `st` holds prev on entry and out on return; returns min_d out.
-template <int NP>
-__device__ __forceinline__ int sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[NP], int prevMin, uint32_t P1v, int P2)
+// in saturating int16 arithmetic.  `st` holds prev on entry and out on return; prevMin and the
+// returned min_d out carry the value in both halves.  `first` / `last` flag the group's end
+// lanes: inside a 16-lane DPP row a shift would otherwise pull in the neighbouring group's value.
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[NP], uint32_t prevMin, const SgmPenalty &k, bool first,
+                                             bool last)
 {
     const uint32_t BIG = 0x7fff7fffu;
-    int mp2 = prevMin + P2;
-    mp2 = mp2 > 32767 ? 32767 : mp2;
-    const uint32_t mp2v = pk_splat(mp2);
-    const uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
-    const uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, st[0]);      // lane+1's bottom pair
+    uint32_t mp2v = pk_adds(prevMin, k.P2a);
+    if (k.P2b) mp2v = pk_adds(pk_adds(mp2v, k.P2b), k.P2c);
+    uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
+    uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, st[0]);      // lane+1's bottom pair
+    if (LPP < 16) {
+        below = first ? BIG : below;
+        above = last ? BIG : above;
+    }
     uint32_t out[NP];
     uint32_t mn = BIG;
 #pragma unroll
@@ -135,14 +163,14 @@ __device__ __forceinline__ int sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[
         const uint32_t hi_src = (p < NP - 1) ? st[p + 1] : above;
         const uint32_t dm1 = __builtin_amdgcn_alignbit(st[p], lo_src, 16); // (prev[d-1]) for both halves
         const uint32_t dp1 = __builtin_amdgcn_alignbit(hi_src, st[p], 16); // (prev[d+1])
-        const uint32_t a = pk_adds(pk_min(dm1, dp1), P1v);
+        const uint32_t a = pk_adds(pk_min(dm1, dp1), k.P1v);
         const uint32_t m = pk_min(a, pk_min(st[p], mp2v));
         out[p] = pk_adds(c[p], pk_subs(m, mp2v));
         mn = pk_min(mn, out[p]);
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = out[p];
-    return row_min_pk(mn);
+    return group_min_splat<LPP>(mn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -189,12 +217,21 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: pixel cost -> box aggregation -> top->down path, one block per (16 columns, stripe, frame)
+// K2: pixel cost -> box aggregation -> top->down path, one block per (256/LPP columns, stripe, frame)
 // ---------------------------------------------------------------------------------------------
+// 2*NP consecutive bytes (one per disparity) from a byte-aligned address into whole registers
 template <int NP>
-__device__ __forceinline__ void load_bytes(const uint8_t *p, uint8_t (&dst)[2 * NP])
+__device__ __forceinline__ void load_bytes(const uint8_t *p, uint32_t (&dst)[(NP + 1) / 2])
 {
+    if (NP & 1) dst[NP / 2] = 0;
     __builtin_memcpy(dst, p, 2 * NP);
+}
+// bytes 2p and 2p+1 of such a register array, widened to a packed pair of u16: one v_perm_b32
+template <int NP>
+__device__ __forceinline__ uint32_t byte_pair(const uint32_t (&w)[(NP + 1) / 2], int p)
+{
+    const uint32_t x = w[p >> 1];
+    return (p & 1) ? __builtin_amdgcn_perm(x, x, 0x0c030c02u) : __builtin_amdgcn_perm(x, x, 0x0c010c00u);
 }
 
 // Birchfield-Tomasi cost of one channel for a packed pair of disparities
@@ -205,19 +242,36 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
     return pku_min(c0, c1);
 }
 
-// Inputs of one image row for the (up to 3) tile columns a DPP row computes pixel costs for.
-template <int NP>
-struct RowInputs {
-    uint2 lr[3];
-    uint8_t q[3][6][2 * NP];
-};
+// LDS footprint of the vertical kernel in u32 words: two input stages, the pixel-cost tile, the ring
+// one stage = 4 byte-shifted copies of the 6 right-image plane runs + the left records; `roles` = words fetched per row
+__host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + 2 * tileC; }
+__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 24 * ((tileC - 1 + D + 3) / 4 + 1) + 2 * tileC; }
+__host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D)
+{
+    const int tileC = 256 / LPP + 2 * SW2;
+    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (size_t)(2 * SH2 + 2) * 256 * NP;
+}
+constexpr int kStageLoadsMax = 3; // staging words per thread and row (host checks the bound)
 
-template <int NP>
+// The inputs of an image row reach the lanes through LDS: the block needs tileC left records and,
+// per right-image plane, one run of tileC-1+D consecutive bytes (all disparities of all its tile
+// columns overlap in it).  Those ~1 KB are fetched once per row by the first few lanes of the block,
+// one row ahead, instead of 2*NP bytes per plane per lane from the vector cache.  A lane's 2*NP
+// bytes start at an arbitrary byte of the run and misaligned LDS reads stall the LDS pipeline, so
+// the run is staged four times, shifted by 0..3 bytes: every lane reads whole aligned words from
+// the copy that matches its offset.
+// Every global access is (block-uniform 64-bit base) + (per-lane 32-bit offset fixed for the whole
+// kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
+template <int NP, int LPP>
 __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol)
 {
+    constexpr int GPB = 256 / LPP;          // image columns per block
+    constexpr int NPS = LPP == 16 ? 3 : 2;  // tile columns per lane group: ceil((GPB + 20) / GPB), blockSize <= 21
+    constexpr int CW = NP * LPP;            // u32 per volume column (= D / 2)
     extern __shared__ uint32_t smem[];
-    const int tid = threadIdx.x, grp = tid >> 4, l = tid & 15;
+    const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
+    const bool first = l == 0, last = l == LPP - 1;
     const int n = blockIdx.y, b = blockIdx.z;
     const int W = g.W, H = g.H, W1 = g.W1, SW2 = g.SW2, SH2 = g.SH2;
     const int start = max(min(n * g.stripe_sz - g.stripe_overlap, H), 0);
@@ -225,124 +279,197 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int own0 = n * g.stripe_sz;
     if (start >= end) return;
     const int NR = 2 * SH2 + 2;
-    const int tileC = 16 + 2 * SW2;           // <= 36 (blockSize <= 21): at most 3 tile columns per DPP row
-    uint32_t *pixT = smem;                    // [tileC][16][NP]
-    uint32_t *ring = smem + tileC * 16 * NP;  // [NR][256][NP], thread-private slots
-    const int xa = blockIdx.x * 16;
+    const int tileC = GPB + 2 * SW2;
+    const int nd = (tileC - 1 + g.D + 3) / 4 + 1;   // u32 words per staged right-image plane
+    const int nroles = 6 * nd + 2 * tileC;          // = vertical_stage_roles(tileC, D)
+    const int stageW = 24 * nd + 2 * tileC;         // = vertical_stage_words(tileC, D)
+    uint32_t *stage = smem;                         // [2][ 4 shifts [6 planes [nd]] | tileC records [2] ]
+    uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
+    uint32_t *ring = pixT + tileC * LPP * NP;       // [NR][256][NP], thread-private slots
+    const int xa = blockIdx.x * GPB;
     const int xc_own = xa + grp;
     const bool active = xc_own < W1;
     const size_t plane = (size_t)W * H;
-    const uint2 *lrec_b = lrec + (size_t)b * plane;
+    const char *lrec_b = reinterpret_cast<const char *>(lrec + (size_t)b * plane);
     const uint8_t *rrev_b = rrev + (size_t)b * 6 * plane;
-    const uint32_t P1v = pk_splat(min(g.P1, 32767));
+    const SgmPenalty pen = make_penalty(g);
 
-    // image column of each tile column this DPP row is responsible for (replicated at the cost-range border)
-    int xin[3];
+    // image column of tile column c (replicated at the border of the cost range)
+    auto tile_x = [&](int c) { return min(max(xa - SW2 + c, 0), W1 - 1) + g.minX1; };
+    const int x_hi = tile_x(tileC - 1);
+    const int rr_lo = W - 1 - x_hi + g.minD;        // mirrored index of the first staged right-image byte
+    // staging roles of this thread: which global word goes to which stage word
+    uint32_t s_goff[kStageLoadsMax], s_lidx[kStageLoadsMax];
+    bool s_left[kStageLoadsMax], s_on[kStageLoadsMax];
 #pragma unroll
-    for (int ps = 0; ps < 3; ps++) {
-        int xc = xa - SW2 + grp + 16 * ps;
-        xc = xc < 0 ? 0 : (xc > W1 - 1 ? W1 - 1 : xc);
-        xin[ps] = xc + g.minX1;
+    for (int e = 0; e < kStageLoadsMax; e++) {
+        const int i = min(tid + 256 * e, nroles - 1);
+        s_on[e] = tid + 256 * e < nroles;
+        s_left[e] = i >= 6 * nd;
+        if (s_left[e]) {
+            const int w = i - 6 * nd;
+            s_lidx[e] = (uint32_t)(24 * nd + w);
+            s_goff[e] = (uint32_t)tile_x(w >> 1) * (uint32_t)sizeof(uint2) + (uint32_t)(w & 1) * 4u;
+        } else {
+            const int j = i / nd, idx = i - j * nd;
+            s_lidx[e] = (uint32_t)i;   // word of the unshifted copy; copy s lies 6 * nd * s words further
+            s_goff[e] = (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
+        }
+    }
+    // byte offset inside a staged plane of the first disparity this lane needs, per tile column
+    uint32_t qword[NPS]; // as a word index into the stage: copy (offset & 3), word (offset >> 2)
+#pragma unroll
+    for (int ps = 0; ps < NPS; ps++) {
+        const int o = x_hi - tile_x(min(grp + GPB * ps, tileC - 1)) + l * 2 * NP;
+        qword[ps] = (uint32_t)((o & 3) * 6 * nd + (o >> 2));
     }
 
     uint32_t Cst[NP], Tst[NP], hs[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = 0; }
-    int topMin = 0;
+    uint32_t topMin = 0;
+    uint32_t sreg[kStageLoadsMax][2];
 
-    auto load_row = [&](int k, RowInputs<NP> &in) {
+    auto stage_fetch = [&](int k) {
+        const char *lrow = lrec_b + (size_t)k * W * sizeof(uint2);
+        const char *rrow = reinterpret_cast<const char *>(rrev_b + (size_t)k * W);
 #pragma unroll
-        for (int ps = 0; ps < 3; ps++) {
-            if (grp + 16 * ps < tileC) {
-                const int x = xin[ps];
-                in.lr[ps] = lrec_b[(size_t)k * W + x];
-                const uint8_t *rp = rrev_b + (size_t)k * W + (W - 1 - x + g.minD + l * 2 * NP);
-#pragma unroll
-                for (int j = 0; j < 6; j++) load_bytes<NP>(rp + j * plane, in.q[ps][j]);
+        for (int e = 0; e < kStageLoadsMax; e++) {
+            if (e * 256 < nroles && s_on[e]) {
+                if (s_left[e]) {
+                    sreg[e][0] = *reinterpret_cast<const uint32_t *>(lrow + s_goff[e]);
+                } else {
+                    uint32_t v[2];
+                    __builtin_memcpy(v, rrow + s_goff[e], 8);
+                    sreg[e][0] = v[0]; sreg[e][1] = v[1];
+                }
             }
         }
     };
-    // pixel costs of the loaded row -> LDS tile -> horizontal box sum for this thread's column
-    auto box_row = [&](int k, const RowInputs<NP> &in) {
-        lds_barrier();
+    auto stage_put = [&](int buf) {
+        uint32_t *st = stage + buf * stageW;
 #pragma unroll
-        for (int ps = 0; ps < 3; ps++) {
-            const int c = grp + 16 * ps;
+        for (int e = 0; e < kStageLoadsMax; e++) {
+            if (e * 256 < nroles && s_on[e]) {
+                st[s_lidx[e]] = sreg[e][0];
+                if (!s_left[e]) {
+                    st[s_lidx[e] + 6 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 1);
+                    st[s_lidx[e] + 12 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 2);
+                    st[s_lidx[e] + 18 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 3);
+                }
+            }
+        }
+    };
+    // pixel costs of the row staged in `buf` -> LDS tile -> horizontal box sum for this thread's column -> ring slot.
+    // Barrier A separates the previous row's tile reads from this row's tile writes (and publishes the
+    // stage written since the last barrier); barrier B publishes the tile.
+    auto box_row = [&](int slot, int buf) {
+        lds_barrier();
+        const uint32_t *st = stage + buf * stageW;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ps++) {
+            const int c = grp + GPB * ps;
             if (c < tileC) {
-                const uint2 lr = in.lr[ps];
+                const uint2 lr = *reinterpret_cast<const uint2 *>(st + 24 * nd + 2 * c);
                 const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
                 const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
+                uint32_t q[6][(NP + 1) / 2];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int w = 0; w < (NP + 1) / 2; w++) q[j][w] = st[j * nd + qword[ps] + w];
+                }
+                Pack<NP> px;
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
                     uint32_t v[6];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v[j] = (uint32_t)in.q[ps][j][2 * p] | ((uint32_t)in.q[ps][j][2 * p + 1] << 16);
+                    for (int j = 0; j < 6; j++) v[j] = byte_pair<NP>(q[j], p);
                     const uint32_t cg = bt_pair(u, u0, u1, v[0], v[1], v[2]);
                     const uint32_t ci = bt_pair(t, t0, t1, v[3], v[4], v[5]);
-                    pixT[(c * 16 + l) * NP + p] = cg + ((ci >> 2) & 0x3fff3fffu);
+                    px.v[p] = cg + ((ci >> 2) & 0x3fff3fffu);
                 }
+                *reinterpret_cast<Pack<NP> *>(pixT + (c * LPP + l) * NP) = px;
             }
         }
         lds_barrier();
+    };
+    auto box_sum = [&](int slot) {
 #pragma unroll
         for (int p = 0; p < NP; p++) hs[p] = 0;
         for (int j = 0; j <= 2 * SW2; j++) {
+            const Pack<NP> px = *reinterpret_cast<const Pack<NP> *>(pixT + ((grp + j) * LPP + l) * NP);
 #pragma unroll
-            for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], pixT[((grp + j) * 16 + l) * NP + p]);
+            for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px.v[p]);
         }
+        Pack<NP> o;
 #pragma unroll
-        for (int p = 0; p < NP; p++) ring[((k % NR) * 256 + tid) * NP + p] = hs[p];
+        for (int p = 0; p < NP; p++) o.v[p] = hs[p];
+        *reinterpret_cast<Pack<NP> *>(ring + (slot * 256 + tid) * NP) = o;
     };
 
-    RowInputs<NP> cur, nxt;
     // cost of the stripe's first row: rows above it replicate that row
     for (int k = start; k <= start + SH2; k++) {
         const int kk = min(k, H - 1);
-        load_row(kk, cur);
-        box_row(kk, cur);
+        stage_fetch(kk);
+        lds_barrier();            // the previous row's stage reads are done
+        stage_put(0);
+        box_row(kk % NR, 0);
+        box_sum(kk % NR);
         const int scale = (k == start) ? SH2 + 1 : 1;
 #pragma unroll
         for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pk_mul(hs[p], scale));
     }
 
-    uint32_t *Cout = Cvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
-    uint32_t *Tout = Tvol + ((size_t)b * H * W1 + xc_own) * (size_t)(16 * NP) + l * NP;
-    // row y needs image row y + 1 + SH2 for the step to y + 1: its inputs are fetched one iteration ahead
-    if (start + 1 < end && start + 1 + SH2 <= H - 1) load_row(start + 1 + SH2, cur);
+    const uint32_t voff = (uint32_t)(((size_t)xc_own * CW + l * NP) * sizeof(uint32_t));
+    const size_t row_bytes = (size_t)W1 * CW * sizeof(uint32_t);
+    char *Cout = reinterpret_cast<char *>(Cvol) + ((size_t)b * H + start) * row_bytes;
+    char *Tout = reinterpret_cast<char *>(Tvol) + ((size_t)b * H + start) * row_bytes;
+    // ring slots (row index mod NR) of the row entering and the row leaving the vertical window
+    int slot_add = (start + 1 + SH2) % NR, slot_sub = start % NR;
+    const int slot_last = (H - 1) % NR;
+    // The step from row y to y + 1 needs image row y + 1 + SH2.  Its inputs are fetched into registers
+    // during iteration y - 1 and put into stage (y & 1) at the top of iteration y, so they are
+    // published by barrier A of iteration y; readers of that stage buffer finished two iterations
+    // earlier.  Waiting for a fetch also waits for every older store, so the wait sits a whole
+    // iteration after both were issued: by then they have long completed.
+    if (start + 1 < end && start + 1 + SH2 <= H - 1) stage_fetch(start + 1 + SH2);
     for (int y = start; y < end; y++) {
+        const bool box_now = (y + 1 < end) && (y + 1 + SH2 <= H - 1);
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
-        if (fetch_next) load_row(y + 2 + SH2, nxt);
-        topMin = sgm_step<NP>(Cst, Tst, topMin, P1v, g.P2);
+        topMin = sgm_step<NP, LPP>(Cst, Tst, topMin, pen, first, last);
+        if (box_now) stage_put(y & 1);
+        if (fetch_next) stage_fetch(y + 2 + SH2);
         if (y >= own0 && active) {
             Pack<NP> pc, pt;
 #pragma unroll
             for (int p = 0; p < NP; p++) { pc.v[p] = Cst[p]; pt.v[p] = Tst[p]; }
-            const size_t off = (size_t)y * W1 * (size_t)(16 * NP);
-            *reinterpret_cast<Pack<NP> *>(Cout + off) = pc;
-            *reinterpret_cast<Pack<NP> *>(Tout + off) = pt;
+            *reinterpret_cast<Pack<NP> *>(Cout + voff) = pc;
+            *reinterpret_cast<Pack<NP> *>(Tout + voff) = pt;
         }
+        Cout += row_bytes;
+        Tout += row_bytes;
         if (y + 1 < end) {
-            const int kadd = y + 1 + SH2;
-            if (kadd <= H - 1) {
-                box_row(kadd, cur);
+            if (box_now) {
+                box_row(slot_add, y & 1);
+                box_sum(slot_add);
             } else {
+                const Pack<NP> o = *reinterpret_cast<const Pack<NP> *>(ring + (slot_last * 256 + tid) * NP);
 #pragma unroll
-                for (int p = 0; p < NP; p++) hs[p] = ring[(((H - 1) % NR) * 256 + tid) * NP + p];
+                for (int p = 0; p < NP; p++) hs[p] = o.v[p];
             }
-            const int ksub = max(y - SH2, start);
+            const Pack<NP> sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const uint32_t sub = ring[((ksub % NR) * 256 + tid) * NP + p];
-                Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub);
-            }
+            for (int p = 0; p < NP; p++) Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub.v[p]);
+            slot_add = slot_add + 1 == NR ? 0 : slot_add + 1;
+            if (y + 1 - SH2 > start) slot_sub = slot_sub + 1 == NR ? 0 : slot_sub + 1;
         }
-        if (fetch_next) cur = nxt;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K3: left->right and right->left paths, sum of the three paths, WTA / uniqueness / sub-pixel.
-// One DPP row (16 lanes) per image row; a 64-thread block covers 4 consecutive rows.
+// One lane group per image row; a 64-thread block covers 64/LPP consecutive rows.
 // The left->right costs are needed in right->left order.  Instead of spilling them to HBM the
 // first sweep stores only its state every SEG columns (checkpoints); the second sweep walks the
 // segments right to left, re-runs the left->right recurrence inside the segment from its
@@ -354,20 +481,22 @@ struct SegLen {
     static constexpr int value = NP <= 2 ? 8 : 4;
 };
 
-// winner-take-all, uniqueness test and parabola fit for one column from the summed costs S
-template <int NP>
-__device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, int grp, size_t col, uint32_t *__restrict__ wta,
-                                           int16_t *__restrict__ dsub)
+// winner-take-all, uniqueness test and parabola fit for one column from the summed costs S.
+// `wcol` / `dcol` point at the column's entry of the block's first row; woff is this lane
+// group's row offset in elements.
+template <int NP, int LPP>
+__device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, int grp, uint32_t woff,
+                                           uint32_t *__restrict__ wcol, int16_t *__restrict__ dcol)
 {
     uint32_t key = 0xffffffffu;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        const v2s s2 = as_v2s(S[p]);
-        const uint32_t k0 = ((uint32_t)((int)s2.x + 32768) << 16) | (uint32_t)(d0 + 2 * p);
-        const uint32_t k1 = ((uint32_t)((int)s2.y + 32768) << 16) | (uint32_t)(d0 + 2 * p + 1);
+        const uint32_t sb = S[p] ^ 0x80008000u; // both halves biased by 32768
+        const uint32_t k0 = (sb << 16) | (uint32_t)(d0 + 2 * p);
+        const uint32_t k1 = (sb & 0xffff0000u) | (uint32_t)(d0 + 2 * p + 1);
         key = min(key, min(k0, k1));
     }
-    key = row_min_u32(key);
+    key = group_min_u32<LPP>(key);
     const int best = (int)(key & 0xffffu);
     const int minS = (int)(key >> 16) - 32768;
     bool reject = false;
@@ -382,9 +511,10 @@ __device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S
             bad |= ((int)s2.y * f < lim) && (abs(db - best) > 1);
         }
         const unsigned long long bal = __ballot(bad);
-        reject = ((bal >> (grp * 16)) & 0xffffull) != 0;
+        reject = ((bal >> (grp * LPP)) & ((1ull << LPP) - 1ull)) != 0;
     }
-    // S shifted by one disparity in both directions, for the parabola fit on the owning lane
+    // S shifted by one disparity in both directions, for the parabola fit on the owning lane.  The
+    // fit never reads below disparity 0 or above D-1, so what the group's end lanes pull in is unused.
     const uint32_t below = dpp_row<DPP_ROW_SHR1>(0u, S[NP - 1]);
     const uint32_t above = dpp_row<DPP_ROW_SHL1>(0u, S[0]);
     if (best >= d0 && best < d0 + 2 * NP) {
@@ -411,37 +541,45 @@ __device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S
             dval = dd + g.minD * 16;
             out_w = key;
         }
-        wta[col] = out_w;
-        dsub[col] = (int16_t)dval;
+        wcol[woff] = out_w;
+        dcol[woff] = (int16_t)dval;
     }
 }
 
-template <int NP>
+template <int NP, int LPP>
 __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
                                                    const uint32_t *__restrict__ Tvol, uint32_t *__restrict__ ckpt,
                                                    uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
 {
     constexpr int SEG = SegLen<NP>::value;
-    const int tid = threadIdx.x, grp = tid >> 4, l = tid & 15;
-    const int row = blockIdx.x * 4 + grp;
-    if (row >= nrows_total) return;
+    constexpr int RPW = 64 / LPP; // image rows per wave
+    constexpr int CW = NP * LPP;  // u32 per volume column
+    const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
+    const bool first = l == 0, last = l == LPP - 1;
+    const int row0 = blockIdx.x * RPW;
+    if (row0 + grp >= nrows_total) return;
     const int W1 = g.W1;
     const int nseg = (W1 + SEG - 1) / SEG;
-    const size_t rs = (size_t)(16 * NP);            // u32 per column
-    const size_t base = (size_t)row * W1 * rs + l * NP;
-    const uint32_t *Cp = Cvol + base;
-    const uint32_t *Tp = Tvol + base;
-    uint32_t *ck = ckpt + (size_t)row * nseg * rs + l * NP;
-    const uint32_t P1v = pk_splat(min(g.P1, 32767));
+    constexpr size_t col_bytes = (size_t)CW * sizeof(uint32_t);
+    // block-uniform bases plus a fixed per-lane byte offset (row inside the block, lane inside the column)
+    const char *Cb = reinterpret_cast<const char *>(Cvol) + (size_t)row0 * W1 * col_bytes;
+    const char *Tb = reinterpret_cast<const char *>(Tvol) + (size_t)row0 * W1 * col_bytes;
+    char *Kb = reinterpret_cast<char *>(ckpt) + (size_t)row0 * nseg * col_bytes;
+    const uint32_t voff = (uint32_t)(((size_t)grp * W1 * CW + l * NP) * sizeof(uint32_t));
+    const uint32_t koff = (uint32_t)(((size_t)grp * nseg * CW + l * NP) * sizeof(uint32_t));
+    const uint32_t woff = (uint32_t)grp * (uint32_t)W1;
+    uint32_t *wrow = wta + (size_t)row0 * W1;
+    int16_t *drow = dsub + (size_t)row0 * W1;
+    const SgmPenalty pen = make_penalty(g);
     const int d0 = l * 2 * NP; // first disparity index held by this lane
-    auto ldC = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Cp + (size_t)min(max(x, 0), W1 - 1) * rs); };
-    auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tp + (size_t)min(max(x, 0), W1 - 1) * rs); };
+    auto ldC = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Cb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
+    auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
 
     // ---- sweep 1: left -> right, keep the state at every segment start ----
     uint32_t st[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = 0;
-    int mn = 0;
+    uint32_t mn = 0;
     Pack<NP> cb[SEG], nb[SEG];
 #pragma unroll
     for (int u = 0; u < SEG; u++) cb[u] = ldC(u);
@@ -449,12 +587,12 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         Pack<NP> o;
 #pragma unroll
         for (int p = 0; p < NP; p++) o.v[p] = st[p];
-        *reinterpret_cast<Pack<NP> *>(ck + (size_t)j * rs) = o;
 #pragma unroll
         for (int u = 0; u < SEG; u++) nb[u] = ldC((j + 1) * SEG + u);
+        *reinterpret_cast<Pack<NP> *>(Kb + (size_t)j * col_bytes + koff) = o; // after the loads: waiting for them leaves this store in flight
 #pragma unroll
         for (int u = 0; u < SEG; u++)
-            if (j * SEG + u < W1) mn = sgm_step<NP>(cb[u].v, st, mn, P1v, g.P2);
+            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cb[u].v, st, mn, pen, first, last);
 #pragma unroll
         for (int u = 0; u < SEG; u++) cb[u] = nb[u];
     }
@@ -463,25 +601,25 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     uint32_t rst[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) rst[p] = 0;
-    int rmn = 0;
+    uint32_t rmn = 0;
     Pack<NP> tb[SEG], ntb[SEG], fs, nfs;
 #pragma unroll
     for (int u = 0; u < SEG; u++) { cb[u] = ldC((nseg - 1) * SEG + u); tb[u] = ldT((nseg - 1) * SEG + u); }
-    fs = *reinterpret_cast<const Pack<NP> *>(ck + (size_t)(nseg - 1) * rs);
+    fs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)(nseg - 1) * col_bytes + koff);
     for (int j = nseg - 1; j >= 0; j--) {
         const int jn = max(j - 1, 0);
 #pragma unroll
         for (int u = 0; u < SEG; u++) { nb[u] = ldC(jn * SEG + u); ntb[u] = ldT(jn * SEG + u); }
-        nfs = *reinterpret_cast<const Pack<NP> *>(ck + (size_t)jn * rs);
+        nfs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)jn * col_bytes + koff);
         // left -> right costs of this segment, recomputed from the checkpoint
         uint32_t fst[NP], mv = 0x7fff7fffu;
 #pragma unroll
         for (int p = 0; p < NP; p++) { fst[p] = fs.v[p]; mv = pk_min(mv, fst[p]); }
-        int fmn = row_min_pk(mv); // the previous minimum is the minimum of the previous state
+        uint32_t fmn = group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP>(cb[u].v, fst, fmn, P1v, g.P2);
+            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cb[u].v, fst, fmn, pen, first, last);
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
@@ -489,11 +627,11 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         for (int u = SEG - 1; u >= 0; u--) {
             const int xc = j * SEG + u;
             if (xc < W1) {
-                rmn = sgm_step<NP>(cb[u].v, rst, rmn, P1v, g.P2);
+                rmn = sgm_step<NP, LPP>(cb[u].v, rst, rmn, pen, first, last);
                 uint32_t S[NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) S[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tb[u].v[p]);
-                wta_column<NP>(g, S, d0, grp, (size_t)row * W1 + xc, wta, dsub);
+                wta_column<NP, LPP>(g, S, d0, grp, woff, wrow + xc, drow + xc);
             }
         }
 #pragma unroll
@@ -745,13 +883,37 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     g->stripe_overlap = (g->SH2 + 1) + (int)std::ceil(0.1 * g->stripe_sz);
     g->speckleWindowSize = p->speckleWindowSize;
     g->speckleRange = p->speckleRange;
-    g->NP = g->D / 32;
+    // 8 lanes per pixel halve the number of wave steps of the two scan kernels; the per-lane state
+    // (NP registers per volume) stays small enough up to 64 disparities.  L3D_SGBM_LPP=8|16 overrides
+    // the choice for experiments where the value divides D into at most 8 pairs per lane.
+    g->LPP = g->D <= 64 ? 8 : 16;
+    if (const char *ov = std::getenv("L3D_SGBM_LPP")) {
+        const int v = std::atoi(ov);
+        if ((v == 8 || v == 16) && g->D % (2 * v) == 0 && g->D / (2 * v) <= 8 && (v == 16 || (g->D / 16) % 2 == 0)) g->LPP = v;
+    }
+    g->NP = g->D / (2 * g->LPP);
     return 0;
 }
 
 } // namespace l3d
 
 using namespace l3d;
+
+// Calls f(integral_constant<NP>, integral_constant<LPP>) for the built kernel variant; false if there is none.
+template <typename F>
+static bool dispatch_variant(int NP, int LPP, F &&f)
+{
+#define L3D_VARIANT(np, lpp)                                                                  \
+    if (NP == np && LPP == lpp) {                                                             \
+        f(std::integral_constant<int, np>{}, std::integral_constant<int, lpp>{});             \
+        return true;                                                                          \
+    }
+    L3D_VARIANT(2, 8) L3D_VARIANT(4, 8) L3D_VARIANT(6, 8) L3D_VARIANT(8, 8)
+    L3D_VARIANT(1, 16) L3D_VARIANT(2, 16) L3D_VARIANT(3, 16) L3D_VARIANT(4, 16)
+    L3D_VARIANT(5, 16) L3D_VARIANT(6, 16) L3D_VARIANT(7, 16) L3D_VARIANT(8, 16)
+#undef L3D_VARIANT
+    return false;
+}
 
 struct l3d_sgbm {
     SgbmGeom g;
@@ -853,7 +1015,12 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
                   height, p->blockSize, g.stripe_overlap, g.stripe_sz);
         return L3D_ERR_UNSUPPORTED;
     }
-    h->lds_vertical = ((size_t)(16 + 2 * g.SW2) * 16 * g.NP + (size_t)(2 * g.SH2 + 2) * 256 * g.NP) * sizeof(uint32_t);
+    h->lds_vertical = vertical_lds_words(g.LPP, g.NP, g.SW2, g.SH2, g.D) * sizeof(uint32_t);
+    if (vertical_stage_roles(256 / g.LPP + 2 * g.SW2, g.D) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
+        delete h;
+        set_error("l3d_sgbm_create: image %dx%d with %d disparities exceeds the input staging of the vertical kernel", width, height, g.D);
+        return L3D_ERR_UNSUPPORTED;
+    }
     if (h->lds_vertical > 160 * 1024) {
         delete h;
         set_error("l3d_sgbm_create: blockSize %d with numDisparities %d needs %zu B of LDS (> 160 KiB)", p->blockSize, g.D, h->lds_vertical);
@@ -871,7 +1038,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     alloc((void **)&h->in_right, B * px);
     alloc((void **)&h->out_disp, B * px * 2);
     alloc((void **)&h->lrec, B * px * sizeof(uint2));
-    alloc((void **)&h->rrev, B * px * 6 + 64);
+    alloc((void **)&h->rrev, B * px * 6 + 1024); // the row staging reads whole words past the last needed byte
     alloc((void **)&h->Cvol, vol);
     alloc((void **)&h->Tvol, vol);
     alloc((void **)&h->Lvol, g.W1 > 0 ? B * height * (size_t)cdiv(g.W1, 4) * g.D * sizeof(int16_t) : 0);
@@ -891,10 +1058,12 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     }
     if (h->lds_vertical > 64 * 1024) {
         // opt in to more than 64 KiB of dynamic LDS per block
-        const void *fns[] = {(const void *)k_cost_vertical<1>, (const void *)k_cost_vertical<2>, (const void *)k_cost_vertical<3>,
-                             (const void *)k_cost_vertical<4>, (const void *)k_cost_vertical<5>, (const void *)k_cost_vertical<6>,
-                             (const void *)k_cost_vertical<7>, (const void *)k_cost_vertical<8>};
-        e = hipFuncSetAttribute(fns[g.NP - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_vertical);
+        const size_t lds = h->lds_vertical;
+        e = hipErrorInvalidValue;
+        dispatch_variant(g.NP, g.LPP, [&](auto np, auto lpp) {
+            e = hipFuncSetAttribute((const void *)k_cost_vertical<decltype(np)::value, decltype(lpp)::value>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
         if (e != hipSuccess) {
             set_error("l3d_sgbm_create: cannot reserve %zu B of LDS: %s", h->lds_vertical, hipGetErrorString(e));
             l3d_sgbm_destroy(h);
@@ -905,15 +1074,15 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     return L3D_OK;
 }
 
-template <int NP, typename Stamp>
+template <int NP, int LPP, typename Stamp>
 static void launch_core(l3d_sgbm *h, int B, hipStream_t s, Stamp &stamp)
 {
     const SgbmGeom &g = h->g;
-    dim3 gv(cdiv(g.W1, 16), 4, B);
-    hipLaunchKernelGGL(k_cost_vertical<NP>, gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
+    dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
+    hipLaunchKernelGGL((k_cost_vertical<NP, LPP>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
     stamp();
     const int nrows = B * g.H;
-    hipLaunchKernelGGL(k_horizontal<NP>, dim3(cdiv(nrows, 4)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
+    hipLaunchKernelGGL((k_horizontal<NP, LPP>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
 }
 
 static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
@@ -947,16 +1116,9 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     hipLaunchKernelGGL(k_prefilter, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
-    switch (g.NP) {
-    case 1: launch_core<1>(h, B, s, stamp); break;
-    case 2: launch_core<2>(h, B, s, stamp); break;
-    case 3: launch_core<3>(h, B, s, stamp); break;
-    case 4: launch_core<4>(h, B, s, stamp); break;
-    case 5: launch_core<5>(h, B, s, stamp); break;
-    case 6: launch_core<6>(h, B, s, stamp); break;
-    case 7: launch_core<7>(h, B, s, stamp); break;
-    case 8: launch_core<8>(h, B, s, stamp); break;
-    default: set_error("sgbm: unsupported NP %d", g.NP); return L3D_ERR_UNSUPPORTED;
+    if (!dispatch_variant(g.NP, g.LPP, [&](auto np, auto lpp) { launch_core<decltype(np)::value, decltype(lpp)::value>(h, B, s, stamp); })) {
+        set_error("sgbm: no kernel variant for %d pairs on %d lanes", g.NP, g.LPP);
+        return L3D_ERR_UNSUPPORTED;
     }
     stamp();
     hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(256), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
