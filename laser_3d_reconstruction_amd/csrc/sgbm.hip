@@ -43,8 +43,10 @@ struct SgbmGeom {
     int minX1, maxX1, W1, invalid16;
     int stripe_sz, stripe_overlap;
     int speckleWindowSize, speckleRange;
-    int LPP; // lanes that share one pixel's disparity vector: 8 or 16
-    int NP;  // packed int16 pairs per lane, D = 2 * NP * LPP
+    // lanes that share one pixel's disparity vector (8 or 16) and packed int16 pairs per lane
+    // (D = 2 * NP * LPP), chosen separately for the vertical and the horizontal kernel: the volumes
+    // between them are plain [column][disparity] arrays either way
+    int LPPv, NPv, LPPh, NPh;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -245,7 +247,14 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
 // LDS footprint of the vertical kernel in u32 words: two input stages, the pixel-cost tile, the ring
 // one stage = 4 byte-shifted copies of the 6 right-image plane runs + the left records; `roles` = words fetched per row
 __host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + 2 * tileC; }
-__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 24 * ((tileC - 1 + D + 3) / 4 + 1) + 2 * tileC; }
+// words between two shifted copies: at least the 6 plane runs, and 16 modulo 64 so that the lane groups of
+// a wave, which read from all four copies at once, spread over all 64 LDS banks
+__host__ __device__ inline int vertical_copy_stride(int tileC, int D)
+{
+    const int w = 6 * ((tileC - 1 + D + 3) / 4 + 1);
+    return (w - 16 + 63) / 64 * 64 + 16;
+}
+__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 4 * vertical_copy_stride(tileC, D) + 2 * tileC; }
 __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D)
 {
     const int tileC = 256 / LPP + 2 * SW2;
@@ -282,8 +291,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int tileC = GPB + 2 * SW2;
     const int nd = (tileC - 1 + g.D + 3) / 4 + 1;   // u32 words per staged right-image plane
     const int nroles = 6 * nd + 2 * tileC;          // = vertical_stage_roles(tileC, D)
-    const int stageW = 24 * nd + 2 * tileC;         // = vertical_stage_words(tileC, D)
-    uint32_t *stage = smem;                         // [2][ 4 shifts [6 planes [nd]] | tileC records [2] ]
+    const int cstride = vertical_copy_stride(tileC, g.D);
+    const int stageW = 4 * cstride + 2 * tileC;     // = vertical_stage_words(tileC, D)
+    uint32_t *stage = smem;                         // [2][ 4 shifts [cstride >= 6 planes [nd]] | tileC records [2] ]
     uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
     uint32_t *ring = pixT + tileC * LPP * NP;       // [NR][256][NP], thread-private slots
     const int xa = blockIdx.x * GPB;
@@ -308,11 +318,11 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         s_left[e] = i >= 6 * nd;
         if (s_left[e]) {
             const int w = i - 6 * nd;
-            s_lidx[e] = (uint32_t)(24 * nd + w);
+            s_lidx[e] = (uint32_t)(4 * cstride + w);
             s_goff[e] = (uint32_t)tile_x(w >> 1) * (uint32_t)sizeof(uint2) + (uint32_t)(w & 1) * 4u;
         } else {
             const int j = i / nd, idx = i - j * nd;
-            s_lidx[e] = (uint32_t)i;   // word of the unshifted copy; copy s lies 6 * nd * s words further
+            s_lidx[e] = (uint32_t)i;   // word of the unshifted copy; copy s lies s * cstride words further
             s_goff[e] = (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
         }
     }
@@ -321,7 +331,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 #pragma unroll
     for (int ps = 0; ps < NPS; ps++) {
         const int o = x_hi - tile_x(min(grp + GPB * ps, tileC - 1)) + l * 2 * NP;
-        qword[ps] = (uint32_t)((o & 3) * 6 * nd + (o >> 2));
+        qword[ps] = (uint32_t)((o & 3) * cstride + (o >> 2));
     }
 
     uint32_t Cst[NP], Tst[NP], hs[NP];
@@ -353,9 +363,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
             if (e * 256 < nroles && s_on[e]) {
                 st[s_lidx[e]] = sreg[e][0];
                 if (!s_left[e]) {
-                    st[s_lidx[e] + 6 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 1);
-                    st[s_lidx[e] + 12 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 2);
-                    st[s_lidx[e] + 18 * nd] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 3);
+                    st[s_lidx[e] + cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 1);
+                    st[s_lidx[e] + 2 * cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 2);
+                    st[s_lidx[e] + 3 * cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 3);
                 }
             }
         }
@@ -370,7 +380,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         for (int ps = 0; ps < NPS; ps++) {
             const int c = grp + GPB * ps;
             if (c < tileC) {
-                const uint2 lr = *reinterpret_cast<const uint2 *>(st + 24 * nd + 2 * c);
+                const uint2 lr = *reinterpret_cast<const uint2 *>(st + 4 * cstride + 2 * c);
                 const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
                 const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
                 uint32_t q[6][(NP + 1) / 2];
@@ -481,12 +491,11 @@ struct SegLen {
     static constexpr int value = NP <= 2 ? 8 : 4;
 };
 
-// winner-take-all, uniqueness test and parabola fit for one column from the summed costs S.
-// `wcol` / `dcol` point at the column's entry of the block's first row; woff is this lane
-// group's row offset in elements.
+// Winner-take-all and uniqueness test for one column from the summed costs S, on all lanes of the
+// group.  Returns the group-uniform key (biased min S << 16 | argmin), or 0xFFFFFFFF when the
+// uniqueness test rejects the column.
 template <int NP, int LPP>
-__device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, int grp, uint32_t woff,
-                                           uint32_t *__restrict__ wcol, int16_t *__restrict__ dcol)
+__device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0)
 {
     uint32_t key = 0xffffffffu;
 #pragma unroll
@@ -497,12 +506,28 @@ __device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S
         key = min(key, min(k0, k1));
     }
     key = group_min_u32<LPP>(key);
+    if (g.uniq <= 0) return key;
     const int best = (int)(key & 0xffffu);
     const int minS = (int)(key >> 16) - 32768;
-    bool reject = false;
-    if (g.uniq > 0) {
+    const int lim = minS * 100, f = 100 - g.uniq;
+    bool reject;
+    if (f > 0) {
+        // some d outside best-1..best+1 has S[d]*f < lim  <=>  the minimum of S outside that window has.
+        // Bit e of `bits` marks entry e of this lane as inside the window; marked entries become 32767.
+        const int r = min(max(best - d0, -2), 2 * NP + 1);
+        const uint32_t bits = (7u << (r + 2)) >> 3;
+        uint32_t acc = 0x7fff7fffu;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * p, 1);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * p + 1, 1);
+            const uint32_t m = (mlo & 0x0000ffffu) | (mhi & 0xffff0000u);
+            acc = pk_min(acc, (S[p] & ~m) | (m & 0x7fff7fffu));
+        }
+        const int m2 = (int)(short)(group_min_splat<LPP>(acc) & 0xffffu);
+        reject = __mul24(m2, f) < lim;
+    } else {
         bool bad = false;
-        const int lim = minS * 100, f = 100 - g.uniq;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const v2s s2 = as_v2s(S[p]);
@@ -510,40 +535,30 @@ __device__ __forceinline__ void wta_column(const SgbmGeom &g, const uint32_t (&S
             bad |= ((int)s2.x * f < lim) && (abs(da - best) > 1);
             bad |= ((int)s2.y * f < lim) && (abs(db - best) > 1);
         }
+        const int grp = (int)(threadIdx.x & 63) / LPP;
         const unsigned long long bal = __ballot(bad);
         reject = ((bal >> (grp * LPP)) & ((1ull << LPP) - 1ull)) != 0;
     }
-    // S shifted by one disparity in both directions, for the parabola fit on the owning lane.  The
-    // fit never reads below disparity 0 or above D-1, so what the group's end lanes pull in is unused.
-    const uint32_t below = dpp_row<DPP_ROW_SHR1>(0u, S[NP - 1]);
-    const uint32_t above = dpp_row<DPP_ROW_SHL1>(0u, S[0]);
-    if (best >= d0 && best < d0 + 2 * NP) {
-        uint32_t out_w = 0xffffffffu;
-        int dval = 0;
-        if (!reject) {
-            int sc = 0, sm = 0, sp = 0;
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const uint32_t lo_src = (p > 0) ? S[p - 1] : below;
-                const uint32_t hi_src = (p < NP - 1) ? S[p + 1] : above;
-                const v2s cur = as_v2s(S[p]);
-                const v2s dm1 = as_v2s(__builtin_amdgcn_alignbit(S[p], lo_src, 16));
-                const v2s dp1 = as_v2s(__builtin_amdgcn_alignbit(hi_src, S[p], 16));
-                if (best == d0 + 2 * p) { sc = cur.x; sm = dm1.x; sp = dp1.x; }
-                if (best == d0 + 2 * p + 1) { sc = cur.y; sm = dm1.y; sp = dp1.y; }
-            }
-            int dd;
-            if (0 < best && best < g.D - 1) {
-                const int denom2 = max(sm + sp - 2 * sc, 1);
-                dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-            } else
-                dd = best * 16;
-            dval = dd + g.minD * 16;
-            out_w = key;
-        }
-        wcol[woff] = out_w;
-        dcol[woff] = (int16_t)dval;
+    return reject ? 0xffffffffu : key;
+}
+
+// Sub-pixel disparity (x16) from the winning cost sc at `best` and its two neighbours:
+// OpenCV's integer parabola fit with the truncating division done in float plus an exact fix-up
+// (numerator and denominator are below 2^24 and the quotient is at most 8 in magnitude).
+__device__ __forceinline__ int subpixel_disp(const SgbmGeom &g, int best, int sm, int sc, int sp)
+{
+    int dd = best * 16;
+    if (0 < best && best < g.D - 1) {
+        const int denom2 = max(sm + sp - 2 * sc, 1);
+        const int num = (sm - sp) * 16 + denom2, den = denom2 * 2;
+        const int a = abs(num);
+        int q = (int)((float)a * __builtin_amdgcn_rcpf((float)den));
+        int r = a - q * den;
+        if (r < 0) { q--; r += den; }
+        if (r >= den) q++;
+        dd += num < 0 ? -q : q;
     }
+    return dd + g.minD * 16;
 }
 
 template <int NP, int LPP>
@@ -554,10 +569,18 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     constexpr int SEG = SegLen<NP>::value;
     constexpr int RPW = 64 / LPP; // image rows per wave
     constexpr int CW = NP * LPP;  // u32 per volume column
+    constexpr int D = 2 * CW;
+    constexpr int REC = D + 8;    // int16 per staged column: the D summed costs and a gap, so best-1 / best+1 stay inside the array
+    // summed costs and keys of one segment, parked for the sub-pixel step that runs once per segment
+    // with one lane per (row, column) instead of once per column with one lane per row
+    __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
+    __shared__ uint32_t sK[RPW * SEG];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     const bool first = l == 0, last = l == LPP - 1;
     const int row0 = blockIdx.x * RPW;
-    if (row0 + grp >= nrows_total) return;
+    // groups past the last row redo the last row (their lanes are needed for the per-segment step) and store nothing
+    const bool row_ok = row0 + grp < nrows_total;
+    const int grp_ld = min(grp, nrows_total - 1 - row0);
     const int W1 = g.W1;
     const int nseg = (W1 + SEG - 1) / SEG;
     constexpr size_t col_bytes = (size_t)CW * sizeof(uint32_t);
@@ -565,15 +588,17 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     const char *Cb = reinterpret_cast<const char *>(Cvol) + (size_t)row0 * W1 * col_bytes;
     const char *Tb = reinterpret_cast<const char *>(Tvol) + (size_t)row0 * W1 * col_bytes;
     char *Kb = reinterpret_cast<char *>(ckpt) + (size_t)row0 * nseg * col_bytes;
-    const uint32_t voff = (uint32_t)(((size_t)grp * W1 * CW + l * NP) * sizeof(uint32_t));
-    const uint32_t koff = (uint32_t)(((size_t)grp * nseg * CW + l * NP) * sizeof(uint32_t));
-    const uint32_t woff = (uint32_t)grp * (uint32_t)W1;
-    uint32_t *wrow = wta + (size_t)row0 * W1;
-    int16_t *drow = dsub + (size_t)row0 * W1;
+    const uint32_t voff = (uint32_t)(((size_t)grp_ld * W1 * CW + l * NP) * sizeof(uint32_t));
+    const uint32_t koff = (uint32_t)(((size_t)grp_ld * nseg * CW + l * NP) * sizeof(uint32_t));
     const SgmPenalty pen = make_penalty(g);
     const int d0 = l * 2 * NP; // first disparity index held by this lane
     auto ldC = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Cb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
     auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
+    // role of this lane in the per-segment step: column u of row e_grp
+    const int e_u = tid % SEG, e_grp = tid / SEG;
+    const bool e_on = tid < RPW * SEG && row0 + e_grp < nrows_total;
+    uint32_t *wrow = wta + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
+    int16_t *drow = dsub + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
 
     // ---- sweep 1: left -> right, keep the state at every segment start ----
     uint32_t st[NP];
@@ -589,7 +614,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         for (int p = 0; p < NP; p++) o.v[p] = st[p];
 #pragma unroll
         for (int u = 0; u < SEG; u++) nb[u] = ldC((j + 1) * SEG + u);
-        *reinterpret_cast<Pack<NP> *>(Kb + (size_t)j * col_bytes + koff) = o; // after the loads: waiting for them leaves this store in flight
+        if (row_ok) *reinterpret_cast<Pack<NP> *>(Kb + (size_t)j * col_bytes + koff) = o;
 #pragma unroll
         for (int u = 0; u < SEG; u++)
             if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cb[u].v, st, mn, pen, first, last);
@@ -628,12 +653,31 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
             const int xc = j * SEG + u;
             if (xc < W1) {
                 rmn = sgm_step<NP, LPP>(cb[u].v, rst, rmn, pen, first, last);
-                uint32_t S[NP];
+                Pack<NP> S;
 #pragma unroll
-                for (int p = 0; p < NP; p++) S[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tb[u].v[p]);
-                wta_column<NP, LPP>(g, S, d0, grp, woff, wrow + xc, drow + xc);
+                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tb[u].v[p]);
+                const uint32_t key = wta_key<NP, LPP>(g, S.v, d0);
+                *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
+                if (first) sK[grp * SEG + u] = key;
             }
         }
+        // per-segment step: one lane per (row, column) fits the parabola and stores the column's result
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const int xc = j * SEG + e_u;
+            if (e_on && xc < W1) {
+                const uint32_t key = sK[tid];
+                int dval = 0;
+                if (key != 0xffffffffu) {
+                    const int best = (int)(key & 0xffffu);
+                    const int16_t *rec = sS + 8 + tid * REC + best;
+                    dval = subpixel_disp(g, best, rec[-1], (int)(key >> 16) - 32768, rec[1]);
+                }
+                wrow[xc] = key;
+                drow[xc] = (int16_t)dval;
+            }
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < SEG; u++) { cb[u] = nb[u]; tb[u] = ntb[u]; }
         fs = nfs;
@@ -883,15 +927,22 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     g->stripe_overlap = (g->SH2 + 1) + (int)std::ceil(0.1 * g->stripe_sz);
     g->speckleWindowSize = p->speckleWindowSize;
     g->speckleRange = p->speckleRange;
-    // 8 lanes per pixel halve the number of wave steps of the two scan kernels; the per-lane state
-    // (NP registers per volume) stays small enough up to 64 disparities.  L3D_SGBM_LPP=8|16 overrides
-    // the choice for experiments where the value divides D into at most 8 pairs per lane.
-    g->LPP = g->D <= 64 ? 8 : 16;
-    if (const char *ov = std::getenv("L3D_SGBM_LPP")) {
-        const int v = std::atoi(ov);
-        if ((v == 8 || v == 16) && g->D % (2 * v) == 0 && g->D / (2 * v) <= 8 && (v == 16 || (g->D / 16) % 2 == 0)) g->LPP = v;
-    }
-    g->NP = g->D / (2 * g->LPP);
+    // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; the
+    // vertical kernel gains from that up to 64 disparities.  The horizontal kernel has one lane
+    // group per image row, so wider groups mean more waves in flight, which it needs more.
+    // L3D_SGBM_LPPV / L3D_SGBM_LPPH = 8|16 override the choice (experiments).
+    auto pick = [&](const char *name, int dflt) {
+        int lpp = dflt;
+        if (const char *ov = std::getenv(name)) {
+            const int v = std::atoi(ov);
+            if ((v == 8 || v == 16) && g->D % (2 * v) == 0 && g->D / (2 * v) <= 8) lpp = v;
+        }
+        return lpp;
+    };
+    g->LPPv = pick("L3D_SGBM_LPPV", g->D <= 64 ? 8 : 16);
+    g->LPPh = pick("L3D_SGBM_LPPH", 16);
+    g->NPv = g->D / (2 * g->LPPv);
+    g->NPh = g->D / (2 * g->LPPh);
     return 0;
 }
 
@@ -1015,8 +1066,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
                   height, p->blockSize, g.stripe_overlap, g.stripe_sz);
         return L3D_ERR_UNSUPPORTED;
     }
-    h->lds_vertical = vertical_lds_words(g.LPP, g.NP, g.SW2, g.SH2, g.D) * sizeof(uint32_t);
-    if (vertical_stage_roles(256 / g.LPP + 2 * g.SW2, g.D) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
+    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.D) * sizeof(uint32_t);
+    if (vertical_stage_roles(256 / g.LPPv + 2 * g.SW2, g.D) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
         delete h;
         set_error("l3d_sgbm_create: image %dx%d with %d disparities exceeds the input staging of the vertical kernel", width, height, g.D);
         return L3D_ERR_UNSUPPORTED;
@@ -1060,7 +1111,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         // opt in to more than 64 KiB of dynamic LDS per block
         const size_t lds = h->lds_vertical;
         e = hipErrorInvalidValue;
-        dispatch_variant(g.NP, g.LPP, [&](auto np, auto lpp) {
+        dispatch_variant(g.NPv, g.LPPv, [&](auto np, auto lpp) {
             e = hipFuncSetAttribute((const void *)k_cost_vertical<decltype(np)::value, decltype(lpp)::value>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         });
@@ -1074,13 +1125,18 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     return L3D_OK;
 }
 
-template <int NP, int LPP, typename Stamp>
-static void launch_core(l3d_sgbm *h, int B, hipStream_t s, Stamp &stamp)
+template <int NP, int LPP>
+static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
     hipLaunchKernelGGL((k_cost_vertical<NP, LPP>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
-    stamp();
+}
+
+template <int NP, int LPP>
+static void launch_horizontal(l3d_sgbm *h, int B, hipStream_t s)
+{
+    const SgbmGeom &g = h->g;
     const int nrows = B * g.H;
     hipLaunchKernelGGL((k_horizontal<NP, LPP>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
 }
@@ -1116,8 +1172,11 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     hipLaunchKernelGGL(k_prefilter, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
-    if (!dispatch_variant(g.NP, g.LPP, [&](auto np, auto lpp) { launch_core<decltype(np)::value, decltype(lpp)::value>(h, B, s, stamp); })) {
-        set_error("sgbm: no kernel variant for %d pairs on %d lanes", g.NP, g.LPP);
+    const bool have_v = dispatch_variant(g.NPv, g.LPPv, [&](auto np, auto lpp) { launch_vertical<decltype(np)::value, decltype(lpp)::value>(h, B, s); });
+    stamp();
+    const bool have_h = dispatch_variant(g.NPh, g.LPPh, [&](auto np, auto lpp) { launch_horizontal<decltype(np)::value, decltype(lpp)::value>(h, B, s); });
+    if (!have_v || !have_h) {
+        set_error("sgbm: no kernel variant for %d disparities", g.D);
         return L3D_ERR_UNSUPPORTED;
     }
     stamp();

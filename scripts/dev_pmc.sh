@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scripts/dev_pmc.sh <tag> "<counters pass 1>" ["<counters pass 2>" ...]; prints per-kernel sums for the two scan kernels
 tag=$1; shift
-export SWEEP_BATCHES=${SWEEP_BATCHES:-64} SWEEP_LPP=${SWEEP_LPP:-8}
+export SWEEP_BATCHES=${SWEEP_BATCHES:-64} SWEEP_LPP=${SWEEP_LPP:-0}
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 n=0

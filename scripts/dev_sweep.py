@@ -16,7 +16,7 @@ from laser_3d_reconstruction_amd.utils import synthetic as S  # noqa: E402
 
 W, H, D, b = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (640, 360, 64, 5)))
 batches = [int(v) for v in os.environ.get("SWEEP_BATCHES", "64,128,256").split(",")]
-lpps = [int(v) for v in os.environ.get("SWEEP_LPP", "8,16").split(",")]
+lpps = [int(v) if v else 0 for v in os.environ.get("SWEEP_LPP", "0").split(",")]  # 0 = library default
 dev = torch.device("cuda", 0)
 frames = [S.stereo_pair(W, H, D, k, laser=False) for k in range(4)]
 gl = np.stack([f[0][:, :, 0] for f in frames])
@@ -25,7 +25,8 @@ kw = dict(minDisparity=0, numDisparities=D, blockSize=b, P1=8 * 3 * b * b, P2=32
           uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, preFilterCap=63, mode=2)
 ref = None
 for lpp in lpps:
-    os.environ["L3D_SGBM_LPP"] = str(lpp)
+    if lpp:
+        os.environ["L3D_SGBM_LPPV"] = os.environ["L3D_SGBM_LPPH"] = str(lpp)
     for B in batches:
         reps = (B + 3) // 4
         L = torch.from_numpy(np.concatenate([gl] * reps)[:B]).to(dev)
