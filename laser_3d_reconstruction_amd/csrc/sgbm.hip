@@ -761,13 +761,19 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
 
 // ---------------------------------------------------------------------------------------------
 // K6: speckle filter = connected components (4-neighbourhood, |a-b| <= maxDiff, pixels equal to
-// newVal excluded), components of at most maxSize pixels are set to newVal.
-// Two-level union-find: each 32x32 tile is labelled and counted in LDS (LDS atomics, no global
-// contention); tile roots are then merged across tile borders in global memory and the tile
-// counts are summed onto the final roots, so global atomics scale with the tile perimeter and
-// the number of tile-level components, not with the pixel count.
+// newVal excluded); components of at most maxSize pixels are set to newVal.
+// Only "is the component larger than maxSize" matters, so almost everything is decided inside a
+// 64x64 tile in LDS:
+//   - rows are split into runs with one ballot per row (no atomics, no pointer chasing); union-find
+//     joins run heads of vertically adjacent rows, once per stretch of adjacent connected columns;
+//   - a tile-level component that does not touch an edge shared with another tile is complete: it is
+//     erased or kept on the spot.  One with more than maxSize pixels is kept whatever lies beyond;
+//   - what remains (small and on a shared edge: "pending") gets global labels.  k_speckle_border
+//     walks the shared edges only and joins pending components, or marks one as large when it
+//     continues into a component already known to be large; k_speckle_sum adds the pixel counts of
+//     the pending tile-level roots onto their final roots; k_speckle_apply erases what stayed small.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST = 32; // speckle tile edge
+constexpr int ST = 64; // speckle tile edge = wave width: one ballot describes one tile row
 
 __device__ __forceinline__ int lds_find(volatile int *L, int i)
 {
@@ -807,88 +813,134 @@ __device__ __forceinline__ void uf_union(int *L, int a, int b)
     }
 }
 
-// labels[i] = global index of the tile-level root of pixel i (-1 for excluded pixels);
-// tsize[i] = fsize[i] = pixel count of the tile-level component rooted at i (0 elsewhere)
-__global__ void __launch_bounds__(256) k_speckle_tile(const int16_t *__restrict__ disp, int W, int H, int newVal, int maxDiff,
-                                                      int *__restrict__ labels, int *__restrict__ tsize, int *__restrict__ fsize)
+// labels[i] = -1 for every pixel that is settled (excluded, erased, or part of a large component),
+// else the global index of the pixel's tile-level root, which holds its own index.  tsize / fsize are
+// written at pending roots only.  Pending roots are appended to pend_list (*pend_count entries).
+__global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp, int W, int H, int newVal, int maxDiff, int maxSize,
+                                                      int *__restrict__ labels, int *__restrict__ tsize, int *__restrict__ fsize,
+                                                      int *__restrict__ pend_list, int *__restrict__ pend_count)
 {
-    __shared__ int lab[ST * ST];
-    __shared__ int cnt[ST * ST];
+    __shared__ int lab[ST * ST];   // run head of a pixel; for run heads: union-find parent
+    __shared__ int cnt[ST * ST];   // at roots: pixel count, bit 31 = touches a shared tile edge
     __shared__ short dv[ST * ST];
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long rowL[ST]; // bit x: pixel x joins its left neighbour
+    __shared__ int plist[256];
+    __shared__ int pn, pbase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * ST;
     const size_t img = (size_t)blockIdx.z * W * H;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
-        const int gx = tx0 + x, gy = ty0 + y;
+    const int gx = tx0 + lane;
+    if (tid == 0) pn = 0;
+    const unsigned long long upto = (2ull << lane) - 1ull; // bits 0..lane
+
+    for (int rr = 0; rr < ST / 4; rr++) {
+        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
         const int v = (gx < W && gy < H) ? (int)disp[img + (size_t)gy * W + gx] : newVal;
+        const int vl = __shfl_up(v, 1);
+        const bool valid = v != newVal;
+        const bool joinL = valid && lane > 0 && vl != newVal && abs(v - vl) <= maxDiff;
+        const unsigned long long mL = __ballot(joinL);
+        if (lane == 0) rowL[y] = mL;
+        const int head = 63 - __clzll((long long)(~mL & upto)); // bit 0 of ~mL is always set
         dv[idx] = (short)v;
-        lab[idx] = (v != newVal) ? idx : -1;
+        lab[idx] = valid ? y * ST + head : -1;
         cnt[idx] = 0;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
-        const int v = dv[idx];
-        if (v == newVal) continue;
-        if (x < ST - 1) { const int u = dv[idx + 1]; if (u != newVal && abs(v - u) <= maxDiff) lds_union(lab, idx, idx + 1); }
-        if (y < ST - 1) { const int u = dv[idx + ST]; if (u != newVal && abs(v - u) <= maxDiff) lds_union(lab, idx, idx + ST); }
+    for (int rr = 0; rr < ST / 4; rr++) {
+        const int y = wv * (ST / 4) + rr, idx = y * ST + lane;
+        if (y + 1 >= ST) break;
+        const int v = dv[idx], vb = dv[idx + ST];
+        const bool joinD = v != newVal && vb != newVal && abs(v - vb) <= maxDiff;
+        const unsigned long long mD = __ballot(joinD);
+        // the join at x is implied by the join at x-1 when both rows continue from x-1 to x
+        const unsigned long long need = mD & ~((mD << 1) & rowL[y] & rowL[y + 1]);
+        if ((need >> lane) & 1ull) lds_union(lab, lab[idx], lab[idx + ST]);
     }
     __syncthreads();
-    int root[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = tid + 256 * k;
-        root[k] = -1;
-        if (lab[idx] >= 0) {
-            root[k] = lds_find(lab, idx);
-            atomicAdd(&cnt[root[k]], 1);
+    for (int rr = 0; rr < ST / 4; rr++) {
+        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
+        const unsigned long long mL = rowL[y];
+        const bool head = dv[idx] != newVal && !((mL >> lane) & 1ull);
+        if (head) {
+            const unsigned long long later = ~mL & ~upto; // run heads (or excluded pixels) right of this lane
+            const int len = (later ? __ffsll((long long)later) - 1 : ST) - lane;
+            const int root = lds_find(lab, idx);
+            lab[idx] = root;
+            atomicAdd(&cnt[root], len);
+            const bool edge = (lane == 0 && tx0 > 0) || (lane + len == ST && tx0 + ST < W) || (y == 0 && ty0 > 0) || (y == ST - 1 && gy + 1 < H);
+            if (edge) atomicOr(&cnt[root], (int)0x80000000);
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = tid + 256 * k, x = idx & (ST - 1), y = idx >> 5;
-        const int gx = tx0 + x, gy = ty0 + y;
+    for (int rr = 0; rr < ST / 4; rr++) {
+        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
         if (gx >= W || gy >= H) continue;
-        const size_t g = img + (size_t)gy * W + gx;
-        const int r = root[k];
-        labels[g] = r < 0 ? -1 : (int)(img + (size_t)(ty0 + (r >> 5)) * W + tx0 + (r & (ST - 1)));
-        const int c = (r == idx) ? cnt[idx] : 0;
-        tsize[g] = c;
-        fsize[g] = c;
+        const size_t gi = img + (size_t)gy * W + gx;
+        int out = -1;
+        const int hd = lab[idx];
+        if (hd >= 0) {
+            const int root = lab[hd];
+            const int c = cnt[root];
+            const int n = c & 0x7fffffff;
+            if (c >= 0) {
+                if (n <= maxSize) disp[gi] = (int16_t)newVal;   // complete and small
+            } else if (n <= maxSize) {                          // small so far, may continue in another tile
+                const int groot = (int)(img + (size_t)(ty0 + (root >> 6)) * W + tx0 + (root & (ST - 1)));
+                out = groot;
+                if (idx == root) {
+                    tsize[gi] = n;
+                    fsize[gi] = n;
+                    plist[atomicAdd(&pn, 1)] = groot;
+                }
+            }
+        }
+        labels[gi] = out;
     }
+    __syncthreads();
+    if (tid == 0 && pn > 0) pbase = atomicAdd(pend_count, pn);
+    __syncthreads();
+    if (tid < pn) pend_list[pbase + tid] = plist[tid];
 }
 
-// joins tile-level components across tile borders
-__global__ void __launch_bounds__(256) k_speckle_border(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int *labels)
+// walks the pixel pairs that straddle an edge between two tiles
+__global__ void __launch_bounds__(256) k_speckle_border(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int maxSize,
+                                                        int *labels, int *tsize, int *fsize)
 {
-    const size_t n = (size_t)W * H * B;
+    const int nv = (W - 1) / ST, nh = (H - 1) / ST; // interior tile edges
+    const int per_img = nv * H + nh * W;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const bool right = ((x & (ST - 1)) == ST - 1) && x + 1 < W;
-    const bool down = ((y & (ST - 1)) == ST - 1) && y + 1 < H;
-    if (!right && !down) return;
-    const int v = disp[i];
-    if (v == newVal) return;
-    if (right) { const int u = disp[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + 1); }
-    if (down) { const int u = disp[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(labels, (int)i, (int)i + W); }
+    if (i >= (size_t)per_img * B) return;
+    const int b = (int)(i / per_img), k = (int)(i % per_img);
+    int xa, ya, step;
+    if (k < nv * H) { xa = (k / H + 1) * ST - 1; ya = k % H; step = 1; }
+    else { const int k2 = k - nv * H; ya = (k2 / W + 1) * ST - 1; xa = k2 % W; step = W; }
+    const size_t a = (size_t)b * W * H + (size_t)ya * W + xa, c = a + step;
+    const int va = disp[a], vc = disp[c];
+    if (va == newVal || vc == newVal || abs(va - vc) > maxDiff) return;
+    const int la = labels[a], lc = labels[c];
+    if (la < 0 && lc < 0) return;                    // two large components: nothing to decide
+    if (la < 0 || lc < 0) {                          // a pending component continues into a large one
+        const int t = la < 0 ? lc : la;
+        atomicMax(tsize + t, maxSize + 1);
+        atomicMax(fsize + t, maxSize + 1);
+        return;
+    }
+    uf_union(labels, la, lc);
 }
 
-// every tile-level root adds its count to the final root of its component and points at it
-__global__ void __launch_bounds__(256) k_speckle_sum(size_t n, int *labels, const int *__restrict__ tsize, int *fsize)
+// every pending tile-level root adds its count to the final root of its component and points at it
+__global__ void __launch_bounds__(256) k_speckle_sum(const int *__restrict__ pend_list, const int *__restrict__ pend_count, int *labels,
+                                                     const int *__restrict__ tsize, int *fsize)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = tsize[i];
-    if (c == 0) return;
-    const int r = uf_find(labels, (int)i);
-    if (r != (int)i) {
-        atomicAdd(fsize + r, c);
-        __hip_atomic_store(labels + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = *pend_count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = pend_list[i];
+        const int r = uf_find(labels, t);
+        if (r != t) {
+            atomicAdd(fsize + r, tsize[t]);
+            __hip_atomic_store(labels + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -896,7 +948,7 @@ __global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, size_t n, 
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int t = labels[i]; // tile-level root of the pixel
+    const int t = labels[i]; // tile-level root of a pending pixel
     if (t < 0) return;
     int r = t, p;
     while ((p = labels[r]) != r) r = p; // at most a few hops: k_speckle_sum pointed tile roots at final roots
@@ -976,7 +1028,7 @@ struct l3d_sgbm {
     uint8_t *rrev = nullptr;
     uint32_t *Cvol = nullptr, *Tvol = nullptr, *Lvol = nullptr, *wta = nullptr;
     int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
-    int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr;
+    int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr, *pend = nullptr;
     size_t lds_vertical = 0;
     // optional per-kernel timing: a ring of event sets, one set per compute call
     static constexpr int NK = 6, RING = 32;
@@ -1020,7 +1072,7 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Lvol,
-                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes};
+                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &set : h->ev)
@@ -1101,6 +1153,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->labels, B * px * 4);
         alloc((void **)&h->sizes, B * px * 4);
         alloc((void **)&h->tsizes, B * px * 4);
+        alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, ST) * 256 + 1) * sizeof(int)); // [0] = count, then the list
     }
     if (e != hipSuccess) {
         set_error("l3d_sgbm_create: allocation failed: %s", hipGetErrorString(e));
@@ -1186,12 +1239,17 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
     stamp();
     if (speckle) {
-        const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange;
+        const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
         const unsigned nb = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, h->labels, h->tsizes, h->sizes);
-        hipLaunchKernelGGL(k_speckle_border, dim3(nb), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, h->labels);
-        hipLaunchKernelGGL(k_speckle_sum, dim3(nb), dim3(256), 0, s, n, h->labels, h->tsizes, h->sizes);
-        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, g.speckleWindowSize, h->labels, h->sizes);
+        const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / ST) * g.W);
+        L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
+                           h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend);
+        if (pairs)
+            hipLaunchKernelGGL(k_speckle_border, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, maxSize,
+                               h->labels, h->tsizes, h->sizes);
+        hipLaunchKernelGGL(k_speckle_sum, dim3(256), dim3(256), 0, s, h->pend + 1, h->pend, h->labels, h->tsizes, h->sizes);
+        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, maxSize, h->labels, h->sizes);
     }
     stamp();
     L3D_HIP_CHECK(hipGetLastError());
