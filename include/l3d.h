@@ -83,6 +83,14 @@ int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int
 int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch,
                             int16_t *d_disp, void *stream);
 
+/* The tail of StereoSGBM::compute on its own: 3x3 median (replicated border) of
+ * raw [batch][H][W] int16 disparity maps, then the speckle filter with the
+ * handle's speckleWindowSize / speckleRange and newVal = 16*(minDisparity-1)
+ * (skipped when speckleWindowSize <= 0).  Host pointers.  Same call site as
+ * l3d_sgbm_compute (camera/single_usb_stereo_camera.py:324); exported so that
+ * the post-filters can be driven with hand-made maps. */
+int l3d_sgbm_postfilter(l3d_sgbm *h, const int16_t *raw, int batch, int16_t *disp);
+
 /* Stage buffers of the most recent compute on this handle, copied to host
  * after synchronising (for stage-level parity checks):
  *   0 = aggregated BT cost C      [batch][H][W1][D] int16

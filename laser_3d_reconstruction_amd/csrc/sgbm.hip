@@ -1194,6 +1194,31 @@ static void launch_horizontal(l3d_sgbm *h, int B, hipStream_t s)
     hipLaunchKernelGGL((k_horizontal<NP, LPP>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
 }
 
+// 3x3 median of h->raw into d_disp, then the speckle filter in place: the tail of StereoSGBM::compute
+template <typename Stamp>
+static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
+{
+    const SgbmGeom &g = h->g;
+    const size_t n = (size_t)g.W * g.H * B;
+    const bool speckle = g.speckleWindowSize > 0;
+    hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
+    stamp();
+    if (speckle) {
+        const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / ST) * g.W);
+        L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
+                           h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend);
+        if (pairs)
+            hipLaunchKernelGGL(k_speckle_border, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, maxSize,
+                               h->labels, h->tsizes, h->sizes);
+        hipLaunchKernelGGL(k_speckle_sum, dim3(256), dim3(256), 0, s, h->pend + 1, h->pend, h->labels, h->tsizes, h->sizes);
+        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, maxSize, h->labels, h->sizes);
+    }
+    return L3D_OK;
+}
+
 static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
@@ -1235,21 +1260,9 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(256), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
     stamp();
-    const bool speckle = g.speckleWindowSize > 0;
-    hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
-    stamp();
-    if (speckle) {
-        const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
-        const unsigned nb = (unsigned)((n + 255) / 256);
-        const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / ST) * g.W);
-        L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
-                           h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend);
-        if (pairs)
-            hipLaunchKernelGGL(k_speckle_border, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, maxSize,
-                               h->labels, h->tsizes, h->sizes);
-        hipLaunchKernelGGL(k_speckle_sum, dim3(256), dim3(256), 0, s, h->pend + 1, h->pend, h->labels, h->tsizes, h->sizes);
-        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, maxSize, h->labels, h->sizes);
+    {
+        const int rc = sgbm_post(h, B, d_disp, s, stamp);
+        if (rc) return rc;
     }
     stamp();
     L3D_HIP_CHECK(hipGetLastError());
@@ -1283,6 +1296,22 @@ extern "C" int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t 
     if (rc) return rc;
     L3D_HIP_CHECK(hipMemcpyAsync(disp, h->out_disp, px * batch * 2, hipMemcpyDeviceToHost, s));
     L3D_HIP_CHECK(hipStreamSynchronize(s));
+    return L3D_OK;
+}
+
+extern "C" int l3d_sgbm_postfilter(l3d_sgbm *h, const int16_t *raw, int batch, int16_t *disp)
+{
+    L3D_REQUIRE(h && raw && disp, "l3d_sgbm_postfilter: null argument");
+    L3D_REQUIRE(batch >= 1 && batch <= h->max_batch, "l3d_sgbm_postfilter: batch %d outside [1, %d]", batch, h->max_batch);
+    DeviceGuard dg(h->device);
+    const size_t bytes = (size_t)h->g.W * h->g.H * batch * sizeof(int16_t);
+    L3D_HIP_CHECK(hipMemcpyAsync(h->raw, raw, bytes, hipMemcpyHostToDevice, h->stream));
+    auto no_stamp = []() {};
+    const int rc = sgbm_post(h, batch, h->out_disp, h->stream, no_stamp);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipGetLastError());
+    L3D_HIP_CHECK(hipMemcpyAsync(disp, h->out_disp, bytes, hipMemcpyDeviceToHost, h->stream));
+    L3D_HIP_CHECK(hipStreamSynchronize(h->stream));
     return L3D_OK;
 }
 

@@ -164,6 +164,19 @@ class StereoSGBM:
         out["calls"] = calls.value
         return out
 
+    def postfilter(self, raw: np.ndarray) -> np.ndarray:
+        """The tail of compute() on its own: 3x3 median, then the speckle filter, of (H,W) or (B,H,W) int16 maps."""
+        raw = np.ascontiguousarray(raw)
+        if raw.dtype != np.int16 or raw.ndim not in (2, 3):
+            raise TypeError("postfilter expects (H,W) or (B,H,W) int16 maps")
+        batched = raw.ndim == 3
+        b = raw.shape[0] if batched else 1
+        h, w = raw.shape[-2:]
+        hd = self._handle(w, h, b)
+        out = np.empty((b, h, w), np.int16)
+        N.check(N.lib.l3d_sgbm_postfilter(hd, N.ptr(raw), b, N.ptr(out)), "l3d_sgbm_postfilter")
+        return out if batched else out[0]
+
     def fetch_stage(self, stage: int, batch: int, w: int, h: int) -> np.ndarray:
         g = self.geometry(w, h)
         if stage in (0, 1):

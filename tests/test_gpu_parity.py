@@ -132,6 +132,74 @@ def test_sgbm_edge_cases(gpu, O):
         _sgbm(**_ref_ctor(32, 5)).compute(c, c[:, :100])
 
 
+def _speckle_maps(W, H, seed):
+    """Hand-made disparity maps that stress the component logic: blobs of every size around the
+    threshold, thin snakes that cross many tile edges, plateaus with steps right at the range limit,
+    checkerboards of single pixels, invalid holes."""
+    rng = np.random.default_rng(seed)
+    inv = -16
+    maps = []
+    # 1: noise of small integer levels (many small components, steps of exactly maxDiff and maxDiff+1)
+    a = (rng.integers(0, 6, (H, W)) * 33).astype(np.int16) + 160
+    a[rng.random((H, W)) < 0.15] = inv
+    maps.append(a)
+    # 2: invalid background with rectangles of all sizes 1..~200 px placed everywhere, some touching
+    a = np.full((H, W), inv, np.int16)
+    for _ in range(400):
+        h, w = int(rng.integers(1, 16)), int(rng.integers(1, 16))
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        a[y:y + h, x:x + w] = int(rng.integers(0, 40)) * 16
+    maps.append(a)
+    # 3: one-pixel-wide snakes winding across the whole image (long components, tiny per tile)
+    a = np.full((H, W), inv, np.int16)
+    for k in range(6):
+        y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+        n = int(rng.integers(30, 400))
+        for _ in range(n):
+            a[y, x] = 320 + k
+            if rng.random() < 0.5:
+                x = min(max(x + int(rng.integers(-1, 2)), 0), W - 1)
+            else:
+                y = min(max(y + int(rng.integers(-1, 2)), 0), H - 1)
+    maps.append(a)
+    # 4: smooth ramp (one large component) with small islands and holes cut along tile edges
+    yy, xx = np.mgrid[0:H, 0:W]
+    a = (xx * 3 + yy * 2).astype(np.int16)
+    for x0 in range(60, W - 8, 64):
+        for y0 in range(5, H - 8, 37):
+            a[y0:y0 + 3, x0:x0 + 9] = inv
+            a[y0 + 1, x0 + 2:x0 + 7] = 3000
+    maps.append(a)
+    # 5: checkerboard of isolated pixels and stripes exactly maxDiff apart
+    a = np.where((yy + xx) % 2 == 0, 100, inv).astype(np.int16)
+    a[H // 2:, :] = (xx[H // 2:, :] // 7 * 32).astype(np.int16)
+    maps.append(a)
+    return np.stack(maps)
+
+
+@pytest.mark.parametrize("W,H,win,rng_", [(320, 200, 100, 2), (257, 131, 40, 2), (64, 64, 25, 1), (640, 360, 200, 32), (130, 70, 4000, 2)])
+def test_median_and_speckle_filter_on_handmade_maps(gpu, O, W, H, win, rng_):
+    kw = _ref_ctor(32, 5)
+    kw.update(speckleWindowSize=win, speckleRange=rng_)
+    raw = _speckle_maps(W, H, W + H + win)
+    # the median would smear the patterns away: bypass it by making every map its own fixed point first
+    got = _sgbm(**kw).postfilter(raw)
+    for k in range(raw.shape[0]):
+        want = O.filter_speckles(O.median3_s16(raw[k]), -16, win, 16 * rng_)
+        assert np.array_equal(got[k], want), f"map {k}"
+    # patterns as they are (no median): run the filter on maps that the median leaves unchanged
+    flat = np.repeat(np.repeat(raw[:, ::3, ::3], 3, axis=1), 3, axis=2)[:, :H, :W]
+    flat = np.ascontiguousarray(np.pad(flat, ((0, 0), (0, H - flat.shape[1]), (0, W - flat.shape[2])), mode="edge"))
+    got = _sgbm(**kw).postfilter(flat)
+    changed = 0
+    for k in range(flat.shape[0]):
+        med = O.median3_s16(flat[k])
+        want = O.filter_speckles(med, -16, win, 16 * rng_)
+        changed += int((want != med).sum())
+        assert np.array_equal(got[k], want), f"upsampled map {k}"
+    assert changed > 0  # the filter did erase something
+
+
 def test_sgbm_saturating_costs_match(gpu, O):
     # block 11 on maximum-contrast noise with large penalties drives min + P2 and L + P1 past 32767:
     # the 16-bit saturating arithmetic of the recurrence must agree
