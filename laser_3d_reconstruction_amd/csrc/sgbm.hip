@@ -1134,8 +1134,11 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     const size_t vol = g.W1 > 0 ? B * height * (size_t)g.W1 * g.D * sizeof(int16_t) : 0;
     const size_t cols = g.W1 > 0 ? B * height * (size_t)g.W1 : 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    // every buffer is cleared once here: the first write to fresh device memory pays for mapping its
+    // pages, and that belongs to set-up, not to the first compute call
     auto alloc = [&](void **ptr, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMalloc(ptr, bytes);
+        if (e == hipSuccess && bytes) e = hipMemsetAsync(*ptr, 0, bytes, h->stream);
     };
     alloc((void **)&h->in_left, B * px);
     alloc((void **)&h->in_right, B * px);
@@ -1155,6 +1158,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->tsizes, B * px * 4);
         alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, ST) * 256 + 1) * sizeof(int)); // [0] = count, then the list
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         set_error("l3d_sgbm_create: allocation failed: %s", hipGetErrorString(e));
         l3d_sgbm_destroy(h);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box: kernel-trace statistics and the two HBM-traffic counter passes of a short
+# bench.py run, leaving the summaries under gpurun_out/profile_<tag>/ for copying into profiles/.
+# usage: scripts/gpu_profile.sh <tag> [bench.py arguments...]
+tag=$1; shift
+ROOT=$GRAFT_REPO_ROOT
+out=$ROOT/gpurun_out/profile_$tag
+rm -rf $out; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o vm -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $out/bench_under_profiler.json 2> $out/stats.err || { tail -5 $out/stats.err; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o vm -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/fetch.err || { tail -5 $out/fetch.err; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o vm -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/write.err || { tail -5 $out/write.err; exit 1; }
+ls $out/stats $out/fetch $out/write
+cat $out/bench_under_profiler.json | tail -1 | cut -c1-400
