@@ -212,6 +212,39 @@ int l3d_simple_extract_device(l3d_simple *h, const uint8_t *d_bgr, int width, in
                               double min_area, double *xy, int *count, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Stereo rectification: maps and bilinear remap.
+ * ------------------------------------------------------------------------- */
+typedef struct l3d_remap l3d_remap;
+
+/* A remapper from caller-supplied float32 maps [height][width] (host pointers),
+ * the form cv2.remap takes them in (camera/single_usb_stereo_camera.py:313-314). */
+int l3d_remap_create(const float *map_x, const float *map_y, int width, int height, int device, l3d_remap **out);
+/* replaces cv2.initUndistortRectifyMap(cameraMatrix, distCoeffs, R, newCameraMatrix,
+ * size, CV_32FC1) (camera/single_usb_stereo_camera.py:190-206): the maps are
+ * computed on the device.  camera_matrix 3x3 row-major; dist_coeffs k1 k2 p1 p2
+ * [k3 [k4 k5 k6 [s1 s2 s3 s4]]] (n_dist = 0, 4, 5, 8 or 12); inv_new_camera_R =
+ * inverse of newCameraMatrix[:, :3] * R, 3x3 row-major (a 3x3 inverse the caller
+ * does on the host). */
+int l3d_remap_create_rectify(const double *camera_matrix, const double *dist_coeffs, int n_dist,
+                             const double *inv_new_camera_R, int width, int height, int device, l3d_remap **out);
+void l3d_remap_destroy(l3d_remap *h);
+/* the float32 maps of the handle, [height][width] each (host pointers) */
+int l3d_remap_fetch_maps(l3d_remap *h, float *map_x, float *map_y);
+/* replaces cv2.remap(src, map_x, map_y, cv2.INTER_LINEAR) with the default constant
+ * border 0 (camera/single_usb_stereo_camera.py:313-314) for `batch` u8 images of
+ * `channels` (1 or 3) interleaved channels.  Strides are in bytes, so one half of a
+ * side-by-side or top-bottom camera frame (the reference's _split_frame, :143-150)
+ * is addressed in place.  dst [batch][height][width][channels] (may be NULL);
+ * gray [batch][height][width] (may be NULL; 3-channel sources only) receives
+ * cvtColor(BGR2GRAY) of the remapped image (:320-321). */
+int l3d_remap_apply(l3d_remap *h, const uint8_t *src, int channels, int src_width, int src_height,
+                    ptrdiff_t src_row_stride, ptrdiff_t src_img_stride, int batch, uint8_t *dst, uint8_t *gray);
+/* same, device-resident operands, enqueued on `stream` */
+int l3d_remap_apply_device(l3d_remap *h, const uint8_t *d_src, int channels, int src_width, int src_height,
+                           ptrdiff_t src_row_stride, ptrdiff_t src_img_stride, int batch, uint8_t *d_dst,
+                           uint8_t *d_gray, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Laser pixel -> 3-D (Reconstructor, core/reconstruction.py).
  * ------------------------------------------------------------------------- */
 /* replaces Reconstructor.reconstruct_from_depth (core/reconstruction.py:145-182).

@@ -109,6 +109,12 @@ def _load():
         "l3d_simple_destroy": (None, [vp]),
         "l3d_simple_extract": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
         "l3d_simple_extract_device": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
+        "l3d_remap_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
+        "l3d_remap_create_rectify": (i, [vp, vp, i, vp, i, i, i, C.POINTER(vp)]),
+        "l3d_remap_destroy": (None, [vp]),
+        "l3d_remap_fetch_maps": (i, [vp, vp, vp]),
+        "l3d_remap_apply": (i, [vp, vp, i, i, i, ss, ss, i, vp, vp]),
+        "l3d_remap_apply_device": (i, [vp, vp, i, i, i, ss, ss, i, vp, vp, vp]),
         "l3d_reconstruct_from_depth": (i, [vp, i, vp, i, i, vp, vp, pi, i]),
         "l3d_reconstruct_plane": (i, [vp, i, vp, vp, i, C.c_double, vp, i]),
     }

@@ -10,9 +10,11 @@ Differences a caller can see:
   * when a ``Config`` is given, its STEREO_* knobs select the matcher parameters
     (the reference prints them but always uses its width rule); without one the
     reference's width rule applies (:239-248).
-  * the rectification maps are not generated here yet (remap is the step before
-    this path); Q may be supplied directly, or is taken from the calibration
-    file's own "Q" entry.
+  * the rectification maps live on the GPU (``rectifier_left`` / ``rectifier_right``);
+    ``map_left_x`` ... are host copies fetched on first use.  R1, R2, P1, P2, Q come
+    from ``rectify.stereo_rectify`` as in the reference (:176-187); a calibration
+    file that carries its own "Q" but no distortion model is still honoured when
+    ``use_file_rectification=True``.
 """
 from __future__ import annotations
 
@@ -23,12 +25,14 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 from .. import ops, stereo
+from . import rectify
 
 
 class SingleUSBStereoCameraManager:
     def __init__(self, camera_id: int = 0, width: int = 640, height: int = 240, fps: int = 30,
                  split_mode: str = 'horizontal', calibration_file: str = 'stereo_calibration.json',
-                 config=None, device: int = 0, frame_source=None, verbose: bool = False, max_batch: int = 1):
+                 config=None, device: int = 0, frame_source=None, verbose: bool = False, max_batch: int = 1,
+                 use_file_rectification: bool = False):
         self.camera_id = camera_id
         self.width = width
         self.height = height
@@ -39,6 +43,7 @@ class SingleUSBStereoCameraManager:
         self.device = device
         self.verbose = verbose
         self.max_batch = max_batch
+        self.use_file_rectification = use_file_rectification
 
         self.cap = frame_source
         self.camera_matrix_left = None
@@ -49,7 +54,7 @@ class SingleUSBStereoCameraManager:
         self.T = None
         self.R1 = self.R2 = self.P1 = self.P2 = self.Q = None
         self.roi_left = self.roi_right = None
-        self.map_left_x = self.map_left_y = self.map_right_x = self.map_right_y = None
+        self.rectifier_left = self.rectifier_right = None
         self.stereo_matcher = None
         self.right_matcher = None
         self.wls_filter = None
@@ -110,13 +115,53 @@ class SingleUSBStereoCameraManager:
             self.dist_coeffs_right = np.array(calib['dist_coeffs_right'])
             self.R = np.array(calib['R'])
             self.T = np.array(calib['T'])
-            for key in ('R1', 'R2', 'P1', 'P2', 'Q'):
-                if key in calib:
+            if self.use_file_rectification and all(k in calib for k in ('R1', 'R2', 'P1', 'P2', 'Q')):
+                for key in ('R1', 'R2', 'P1', 'P2', 'Q'):
                     setattr(self, key, np.array(calib[key], dtype=np.float64))
+            else:
+                image_size = (self.single_width, self.single_height)
+                self.R1, self.R2, self.P1, self.P2, self.Q, self.roi_left, self.roi_right = rectify.stereo_rectify(
+                    self.camera_matrix_left, self.dist_coeffs_left, self.camera_matrix_right, self.dist_coeffs_right,
+                    image_size, self.R, self.T, flags=rectify.CALIB_ZERO_DISPARITY, alpha=0)
+            self.rectifier_left = self.rectifier_right = None  # built on the device at first use
             return True
         except Exception as e:  # same convention as the reference: report and fall back
             self._log(f"calibration load failed: {e}")
             return False
+
+    def _ensure_rectifiers(self) -> bool:
+        """cv2.initUndistortRectifyMap for both eyes (reference :190-206), on the device."""
+        if self.R1 is None or self.P1 is None:
+            return False
+        if self.rectifier_left is None:
+            size = (self.single_width, self.single_height)
+            self.rectifier_left = rectify.Rectifier.from_calibration(self.camera_matrix_left, self.dist_coeffs_left, self.R1, self.P1,
+                                                                    size, device=self.device)
+            self.rectifier_right = rectify.Rectifier.from_calibration(self.camera_matrix_right, self.dist_coeffs_right, self.R2, self.P2,
+                                                                     size, device=self.device)
+        return True
+
+    @property
+    def map_left_x(self):
+        return self.rectifier_left.maps[0] if self._ensure_rectifiers() else None
+
+    @property
+    def map_left_y(self):
+        return self.rectifier_left.maps[1] if self._ensure_rectifiers() else None
+
+    @property
+    def map_right_x(self):
+        return self.rectifier_right.maps[0] if self._ensure_rectifiers() else None
+
+    @property
+    def map_right_y(self):
+        return self.rectifier_right.maps[1] if self._ensure_rectifiers() else None
+
+    def rectify_pair(self, left_img: np.ndarray, right_img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """cv2.remap of both eyes (reference :312-317); the images pass through unchanged without a calibration."""
+        if not self._ensure_rectifiers():
+            return np.ascontiguousarray(left_img), np.ascontiguousarray(right_img)
+        return self.rectifier_left.remap(left_img), self.rectifier_right.remap(right_img)
 
     def _use_default_calibration(self):
         fx = fy = 350.0
@@ -183,8 +228,7 @@ class SingleUSBStereoCameraManager:
         if not ret:
             return None, None
         left_img, right_img = self._split_frame(frame)
-        left_rectified = np.ascontiguousarray(left_img)
-        right_rectified = np.ascontiguousarray(right_img)
+        left_rectified, right_rectified = self.rectify_pair(left_img, right_img)
         depth_map = self.compute_depth(left_rectified, right_rectified)
         return left_rectified, depth_map
 

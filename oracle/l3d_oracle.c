@@ -1146,3 +1146,71 @@ ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_s
     free(gray); free(m0); free(m1); free(fin); free(f); free(comp); free(outer); free(stack); free(chain); free(cross_x);
     return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Rectification: cv2.initUndistortRectifyMap + cv2.remap(INTER_LINEAR)      */
+/* (camera/single_usb_stereo_camera.py:190-206, 313-314).  Parity unpinned:  */
+/* restated from OpenCV 4.x modules/calib3d/src/undistort.dispatch.cpp and   */
+/* modules/imgproc/src/imgwarp.cpp.                                          */
+/* ------------------------------------------------------------------------ */
+
+/* Map of the rectified pixel (j, i) into the distorted source image.
+ * K: 3x3 camera matrix (row major); dist: k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+ * (12 doubles, unused ones 0); iR: inverse of (newCameraMatrix[:, :3] * R).
+ * OpenCV's scalar loop accumulates _x += ir[0] along a row while its vector
+ * paths multiply; the product form j*ir[0] + (i*ir[1] + ir[2]) is used here. */
+ORC_API void orc_init_undistort_rectify_map(const double *K, const double *dist, const double *iR, int W, int H,
+                                            float *mapx, float *mapy)
+{
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4], k4 = dist[5], k5 = dist[6], k6 = dist[7];
+    const double s1 = dist[8], s2 = dist[9], s3 = dist[10], s4 = dist[11];
+    for (int i = 0; i < H; i++) {
+        for (int j = 0; j < W; j++) {
+            const double _x = j * iR[0] + (i * iR[1] + iR[2]);
+            const double _y = j * iR[3] + (i * iR[4] + iR[5]);
+            const double _w = j * iR[6] + (i * iR[7] + iR[8]);
+            const double w = 1. / _w, x = _x * w, y = _y * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
+            mapx[(size_t)i * W + j] = (float)(fx * xd + u0);
+            mapy[(size_t)i * W + j] = (float)(fy * yd + v0);
+        }
+    }
+}
+
+/* remap of a u8 image with `ch` interleaved channels, float32 maps, bilinear, constant border 0.
+ * OpenCV turns the maps into fixed point first: s = cvRound(map * 32) (round half to even), integer part
+ * s >> 5 saturated to int16, fraction s & 31; the four tap weights are (32-fx)(32-fy)*32 ... fx*fy*32 (they
+ * sum to 2^15 exactly, so the table's sum correction never fires) and the result is (sum + 2^14) >> 15. */
+static inline int remap_fix(float m)
+{
+    const double v = (double)(m * 32.0f);
+    if (!(v > -2147483648.0 && v < 2147483647.0)) return INT_MIN; /* NaN / overflow: cvtsd2si's "integer indefinite" */
+    return (int)nearbyint(v);
+}
+static inline int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+ORC_API void orc_remap_bilinear_u8(const uint8_t *src, int sw, int sh, int ch, const float *mapx, const float *mapy,
+                                   int dw, int dh, uint8_t *dst)
+{
+    for (int i = 0; i < dh; i++) {
+        for (int j = 0; j < dw; j++) {
+            const int sx = remap_fix(mapx[(size_t)i * dw + j]), sy = remap_fix(mapy[(size_t)i * dw + j]);
+            const int fx = sx & 31, fy = sy & 31;
+            const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            for (int c = 0; c < ch; c++) {
+                int p[4];
+                for (int t = 0; t < 4; t++) {
+                    const int x = ix + (t & 1), y = iy + (t >> 1);
+                    p[t] = (x >= 0 && x < sw && y >= 0 && y < sh) ? src[((size_t)y * sw + x) * ch + c] : 0;
+                }
+                dst[((size_t)i * dw + j) * ch + c] = (uint8_t)((p[0] * w00 + p[1] * w01 + p[2] * w10 + p[3] * w11 + (1 << 14)) >> 15);
+            }
+        }
+    }
+}

@@ -298,3 +298,40 @@ def simple_extract(bgr: np.ndarray, hsv_lower=(40, 50, 100), hsv_upper=(80, 255,
         raise RuntimeError("orc_simple_extract failed")
     pts = xy[: n.value].copy()
     return (pts, masks) if want_masks else pts
+
+
+def dist12(dist) -> np.ndarray:
+    """Distortion coefficients in OpenCV order (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]]) padded to 12."""
+    d = np.asarray(dist, np.float64).reshape(-1)
+    if d.size not in (4, 5, 8, 12):
+        raise ValueError(f"{d.size} distortion coefficients")
+    out = np.zeros(12)
+    out[: d.size] = d
+    return out
+
+
+def init_undistort_rectify_map(K, dist, R, P, size):
+    """cv2.initUndistortRectifyMap(K, dist, R, P, (w, h), CV_32FC1) -> (map_x, map_y) float32 (h, w)."""
+    w, h = size
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+    iR = np.ascontiguousarray(np.linalg.inv(np.asarray(P, np.float64)[:3, :3] @ np.asarray(R, np.float64).reshape(3, 3)))
+    d = dist12(dist)
+    mx = np.empty((h, w), np.float32)
+    my = np.empty((h, w), np.float32)
+    lib().orc_init_undistort_rectify_map(_p(K, C.c_double), _p(d, C.c_double), _p(iR, C.c_double), w, h,
+                                         _p(mx, C.c_float), _p(my, C.c_float))
+    return mx, my
+
+
+def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.ndarray:
+    """cv2.remap(src, map_x, map_y, cv2.INTER_LINEAR) for uint8 (H,W) or (H,W,C), constant border 0."""
+    src = np.ascontiguousarray(src, np.uint8)
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    sh, sw = src.shape[:2]
+    mx = np.ascontiguousarray(map_x, np.float32)
+    my = np.ascontiguousarray(map_y, np.float32)
+    dh, dw = mx.shape
+    dst = np.empty((dh, dw) + (() if src.ndim == 2 else (ch,)), np.uint8)
+    lib().orc_remap_bilinear_u8(_p(src, C.c_uint8), sw, sh, ch, _p(mx, C.c_float), _p(my, C.c_float), dw, dh,
+                                _p(dst, C.c_uint8))
+    return dst

@@ -5,7 +5,7 @@ Corrections (MI355X / gfx950): both counters are in KiB; FETCH_SIZE tallies 128-
 at 64 bytes, i.e. reports half the bytes of a coalesced streaming read, so it is doubled (checked
 here on k_bgr2gray: 3 B/pixel read -> FETCH_SIZE*2*1024 == 3*W*H*B); WRITE_SIZE is exact.
 
-usage: pmc_to_traffic.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv> [tag]
+usage: pmc_to_traffic.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv> [tag] [batch]
 """
 import collections
 import csv
@@ -15,6 +15,7 @@ import sys
 
 cfg, ffile, wfile = sys.argv[1:4]
 tag = sys.argv[4] if len(sys.argv) > 4 else "r1"
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -39,6 +40,7 @@ out["k_speckle_*"] = {"hbm_bytes": sum(out[k]["hbm_bytes"] for k in sp)}
 path = os.path.join(root, "profiles", "traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 data[cfg] = {k: v["hbm_bytes"] for k, v in out.items()}
+data[cfg + "_batch"] = batch
 data[cfg + "_detail_" + tag] = out
 json.dump(data, open(path, "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes"]):

@@ -155,9 +155,92 @@ def test_camera_manager_loads_reference_style_calibration(tmp_path):
     f.write_text(json.dumps(calib))
     cam = SingleUSBStereoCameraManager(calibration_file=str(f))
     assert cam._load_calibration()
+    # like the reference (camera/single_usb_stereo_camera.py:176-187) the rectification is recomputed from
+    # K, dist, R, T; whatever R1/P1/Q the file carries is ignored
     k = cam.get_camera_intrinsics()
-    assert k["fx"] == 209.0 and k["cy"] == 119.5 and abs(k["baseline"] - np.linalg.norm(calib["T"])) < 1e-12
-    assert cam.Q.shape == (4, 4)
+    assert k["fx"] == k["fy"] == cam.P1[0, 0] == cam.P2[0, 0] and k["fx"] != 209.0
+    assert abs(k["baseline"] - np.linalg.norm(calib["T"])) < 1e-12
+    assert cam.Q.shape == (4, 4) and cam.Q[2, 3] == cam.P1[0, 0] and cam.Q[0, 3] == -cam.P1[0, 2]
+    assert abs(cam.P2[0, 3] / cam.P2[0, 0] + np.linalg.norm(calib["T"])) < 1e-6     # Tx * f, rotated baseline
+    assert cam.roi_left[2] > 300 and cam.roi_left[3] > 220
+
+
+def _random_rig(rng):
+    from laser_3d_reconstruction_amd.camera import rectify as RC
+
+    K1 = np.array([[400 + rng.uniform(-20, 20), 0, 320 + rng.uniform(-15, 15)], [0, 405 + rng.uniform(-20, 20), 180 + rng.uniform(-10, 10)], [0, 0, 1]])
+    K2 = np.array([[400 + rng.uniform(-20, 20), 0, 320 + rng.uniform(-15, 15)], [0, 405 + rng.uniform(-20, 20), 180 + rng.uniform(-10, 10)], [0, 0, 1]])
+    R = RC.rodrigues_to_matrix(rng.uniform(-0.03, 0.03, 3))
+    T = np.array([-0.06 + rng.uniform(-0.005, 0.005), rng.uniform(-0.002, 0.002), rng.uniform(-0.002, 0.002)])
+    D1 = np.array([rng.uniform(-0.1, 0.05), rng.uniform(-0.05, 0.1), rng.uniform(-1e-3, 1e-3), rng.uniform(-1e-3, 1e-3), 0.0])
+    D2 = np.array([rng.uniform(-0.1, 0.05), rng.uniform(-0.05, 0.1), rng.uniform(-1e-3, 1e-3), rng.uniform(-1e-3, 1e-3), 0.0])
+    return K1, D1, K2, D2, R, T
+
+
+def test_stereo_rectify_geometry():
+    """Properties cv2.stereoRectify guarantees (no OpenCV here to compare numbers with): R1, R2 are rotations,
+    both rectified cameras share one focal length and (ZERO_DISPARITY) one principal point, every scene point
+    lands on the same row in both views, its column difference is -Tx*f/Z, Q inverts that, alpha=0 keeps only
+    valid pixels."""
+    from laser_3d_reconstruction_amd.camera import rectify as RC
+
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        K1, D1, K2, D2, R, T = _random_rig(rng)
+        if trial == 4:      # vertical rig
+            T = np.array([0.001, -0.07, 0.002])
+        R1, R2, P1, P2, Q, roi1, roi2 = RC.stereo_rectify(K1, D1, K2, D2, (640, 360), R, T, alpha=0)
+        for Rk in (R1, R2):
+            assert np.allclose(Rk @ Rk.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(Rk) - 1) < 1e-12
+        assert P1[0, 0] == P1[1, 1] == P2[0, 0] == P2[1, 1] > 0
+        assert np.array_equal(P1[:, :3], P2[:, :3])
+        idx = 1 if trial == 4 else 0
+        assert P2[idx, 3] != 0 and P2[1 - idx, 3] == 0 and np.all(P1[:, 3] == 0)
+        assert abs(abs(P2[idx, 3]) / P2[0, 0] - np.linalg.norm(T)) < 1e-9       # the whole baseline lies along the axis
+        X = np.c_[rng.uniform(-0.4, 0.4, 50), rng.uniform(-0.3, 0.3, 50), rng.uniform(0.4, 3.0, 50)]   # left camera frame
+        a = (R1 @ X.T).T                                  # rectified left frame
+        b = (R2 @ ((R @ X.T).T + T).T).T                  # rectified right frame
+        assert np.allclose(b - a, (R2 @ T)[None, :], atol=1e-12) and abs((R2 @ T)[1 - idx]) < 1e-12 and abs((R2 @ T)[2]) < 1e-12
+        ua = (P1 @ np.c_[a, np.ones(50)].T).T
+        ub = (P2 @ np.c_[a, np.ones(50)].T).T
+        ua, ub = ua[:, :2] / ua[:, 2:], ub[:, :2] / ub[:, 2:]
+        assert np.abs(ua[:, 1 - idx] - ub[:, 1 - idx]).max() < 1e-9
+        d = ua[:, idx] - ub[:, idx]
+        assert np.allclose(d, -P2[idx, 3] / a[:, 2], rtol=1e-12)
+        if idx == 0:
+            h = np.c_[ua, d, np.ones(50)] @ Q.T
+            assert np.abs(h[:, :3] / h[:, 3:] - a).max() < 1e-9
+        for roi in (roi1, roi2):
+            assert roi[0] >= 0 and roi[1] >= 0 and roi[0] + roi[2] <= 640 and roi[1] + roi[3] <= 360 and roi[2] > 500 and roi[3] > 250
+    # identical ideal cameras, pure x translation: nothing to rotate
+    K = np.array([[350.0, 0, 160], [0, 350.0, 120], [0, 0, 1]])
+    R1, R2, P1, P2, Q, roi1, roi2 = RC.stereo_rectify(K, np.zeros(5), K, np.zeros(5), (320, 240), np.eye(3), [-0.06, 0, 0], alpha=0)
+    assert np.allclose(R1, np.eye(3)) and np.allclose(R2, np.eye(3))
+    assert abs(P2[0, 3] + 0.06 * P1[0, 0]) < 1e-12 and abs(Q[3, 2] - 1 / 0.06) < 1e-9
+
+
+def test_rodrigues_and_undistort_points_roundtrip():
+    from laser_3d_reconstruction_amd.camera import rectify as RC
+
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        om = rng.normal(size=3)
+        om *= rng.uniform(0, 3.1) / np.linalg.norm(om)      # rotation angle below pi: the vector form is unique
+        Rm = RC.rodrigues_to_matrix(om)
+        assert np.allclose(Rm @ Rm.T, np.eye(3), atol=1e-13)
+        assert np.allclose(RC.rodrigues_to_vector(Rm), om, atol=1e-9)
+    assert np.array_equal(RC.rodrigues_to_matrix(np.zeros(3)), np.eye(3))
+    # distort normalised points with the forward model, undistort_points must bring them back (5 iterations: ~1e-6)
+    K = np.array([[400.0, 0, 320], [0, 410.0, 180], [0, 0, 1]])
+    dist = np.array([-0.08, 0.05, 1e-3, -5e-4, 0.01])
+    xy = rng.uniform(-0.5, 0.5, (30, 2))
+    k1, k2, p1, p2, k3 = dist
+    r2 = (xy ** 2).sum(1)
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = xy[:, 0] * kr + 2 * p1 * xy[:, 0] * xy[:, 1] + p2 * (r2 + 2 * xy[:, 0] ** 2)
+    yd = xy[:, 1] * kr + p1 * (r2 + 2 * xy[:, 1] ** 2) + 2 * p2 * xy[:, 0] * xy[:, 1]
+    px = np.c_[xd * 400 + 320, yd * 410 + 180]
+    assert np.abs(RC.undistort_points(px, K, dist) - xy).max() < 2e-5
 
 
 def test_reconstructor_host_helpers():

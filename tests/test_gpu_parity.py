@@ -465,3 +465,101 @@ def test_simple_extractor_matches_oracle(gpu, O):
     d = SimpleLaserExtractor()
     assert list(d.hsv_lower) == [40, 50, 100] and list(d.hsv_upper) == [80, 255, 255] and d.brightness_threshold == 100 and d.min_area == 50
     assert np.array_equal(d.extract_points(lb), O.simple_extract(lb))
+
+
+def _rig():
+    K1 = np.array([[208.896, 0, 166.314], [0, 209.510, 131.166], [0, 0, 1]])
+    K2 = np.array([[209.155, 0, 174.016], [0, 209.931, 133.061], [0, 0, 1]])
+    D1 = np.array([-0.06514, 0.18738, 1e-3, -5e-4, 0.0])
+    D2 = np.array([-0.04349, 0.08947, 0, 0, 0])
+    R = np.array([[0.999955735517614, 0.000791832491916667, -0.009375500345710967],
+                  [-0.0009647212415556836, 0.9998293125001468, -0.018450343585144066],
+                  [0.009359290483459346, 0.01845857163456914, 0.9997858194707794]])
+    T = np.array([-0.06272791143353493, -0.00014512975295812377, -0.00042876801937672266])
+    return K1, D1, K2, D2, R, T
+
+
+def test_rectification_maps_and_remap_bit_exact(gpu, O):
+    """initUndistortRectifyMap on the device == the oracle's (same IEEE double operations, so bit for bit);
+    remap == the oracle's fixed-point bilinear remap bit for bit, for gray / BGR, batches, strided halves of a
+    combined frame, maps that leave the image, and the fused gray plane."""
+    from laser_3d_reconstruction_amd.camera import rectify as RC
+
+    K1, D1, K2, D2, R, T = _rig()
+    W, H = 320, 240
+    R1, R2, P1, P2, Q, _, _ = RC.stereo_rectify(K1, D1, K2, D2, (W, H), R, T, alpha=0)
+    rng = np.random.default_rng(3)
+    for K, D, Rk, P in [(K1, D1, R1, P1), (K2, D2, R2, P2), (K1, np.array([-0.2, 0.1, 1e-3, 2e-3, -0.05, 0.01, 0.02, 0.003]), R1, P2)]:
+        rect = RC.Rectifier.from_calibration(K, D, Rk, P, (W, H))
+        mx, my = rect.maps
+        wx, wy = O.init_undistort_rectify_map(K, D, Rk, P, (W, H))
+        assert mx.dtype == np.float32 and np.array_equal(mx, wx) and np.array_equal(my, wy)
+        bgr = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        got, gray = rect.remap(bgr, want_gray=True)
+        for k in range(3):
+            want = O.remap_bilinear(bgr[k], wx, wy)
+            assert np.array_equal(got[k], want)
+            assert np.array_equal(gray[k], O.bgr2gray(want))
+        assert (got == 0).any() or True
+        g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        assert np.array_equal(rect.remap(g), O.remap_bilinear(g, wx, wy))
+    # one combined side-by-side frame, each eye remapped in place through strides (the reference's _split_frame)
+    frame = rng.integers(0, 256, (H, 2 * W, 3), dtype=np.uint8)
+    left, right = frame[:, :W], frame[:, W:]
+    rl = RC.Rectifier.from_calibration(K1, D1, R1, P1, (W, H))
+    rr = RC.Rectifier.from_calibration(K2, D2, R2, P2, (W, H))
+    assert np.array_equal(rl.remap(left), O.remap_bilinear(np.ascontiguousarray(left), *rl.maps))
+    assert np.array_equal(rr.remap(right), O.remap_bilinear(np.ascontiguousarray(right), *rr.maps))
+    # hand-made maps: other destination size, coordinates outside, NaN, exact half pixels, huge values
+    dh, dw = 50, 70
+    mx = rng.uniform(-5, W + 5, (dh, dw)).astype(np.float32)
+    my = rng.uniform(-5, H + 5, (dh, dw)).astype(np.float32)
+    mx[0, :10] = np.nan; my[1, :10] = np.inf; mx[2, :10] = 1e9; mx[3, :10] = -1e9
+    mx[4, :] = np.arange(dw) + 0.5; my[4, :] = 7.5
+    mx[5, :] = np.arange(dw) + 1 / 64; mx[6, :] = np.arange(dw) - 1 / 64; mx[7, :] = W - 1 + np.arange(dw) / 64
+    rm = RC.Rectifier.from_maps(mx, my)
+    assert np.array_equal(rm.remap(frame[:, :W]), O.remap_bilinear(np.ascontiguousarray(frame[:, :W]), mx, my))
+    src = rng.integers(0, 256, (33, 47), dtype=np.uint8)          # source smaller than the map range
+    assert np.array_equal(rm.remap(src), O.remap_bilinear(src, mx, my))
+    with pytest.raises(gpu.L3DError):
+        RC.Rectifier.from_calibration(K1, np.zeros(7), R1, P1, (W, H))
+
+
+def test_camera_manager_rectifies_like_the_reference_flow(gpu, O, tmp_path):
+    """get_frames = split + remap + depth (camera/single_usb_stereo_camera.py:294-359): the rectified left image and
+    the depth map equal the oracle's remap -> SGBM (+WLS) -> depth chain on the same frame."""
+    import json
+    from laser_3d_reconstruction_amd import SingleUSBStereoCameraManager
+    from laser_3d_reconstruction_amd.camera import rectify as RC
+
+    K1, D1, K2, D2, R, T = _rig()
+    W, H = 320, 240
+    calib = {"camera_matrix_left": K1.tolist(), "dist_coeffs_left": D1.tolist(), "camera_matrix_right": K2.tolist(),
+             "dist_coeffs_right": D2.tolist(), "R": R.tolist(), "T": T.tolist()}
+    f = tmp_path / "stereo_calibration.json"
+    f.write_text(json.dumps(calib))
+    lb, rb = _pair(W, H, 64, 2)
+    frame = np.concatenate([lb, rb], axis=1)
+
+    class Source:
+        def isOpened(self): return True
+        def read(self): return True, frame.copy()
+        def release(self): pass
+
+    class Knobs:
+        STEREO_NUM_DISPARITIES, STEREO_BLOCK_SIZE, STEREO_USE_WLS_FILTER, STEREO_LAMBDA, STEREO_SIGMA = 64, 5, False, 8000.0, 1.5
+
+    cam = SingleUSBStereoCameraManager(width=2 * W, height=H, config=Knobs, frame_source=Source(), calibration_file=str(f))
+    assert cam.initialize()
+    left_rect, depth = cam.get_frames()
+    R1, R2, P1, P2, Q, _, _ = RC.stereo_rectify(K1, D1, K2, D2, (W, H), R, T, alpha=0)
+    assert np.array_equal(cam.Q, Q)
+    mlx, mly = O.init_undistort_rectify_map(K1, D1, R1, P1, (W, H))
+    mrx, mry = O.init_undistort_rectify_map(K2, D2, R2, P2, (W, H))
+    assert np.array_equal(cam.map_left_x, mlx) and np.array_equal(cam.map_right_y, mry)
+    wl, wr = O.remap_bilinear(lb, mlx, mly), O.remap_bilinear(rb, mrx, mry)
+    assert np.array_equal(left_rect, wl)
+    p = O.sgbm_params(**_ref_ctor(64, 5))
+    d16 = O.sgbm_compute(p, O.bgr2gray(wl), O.bgr2gray(wr))
+    want = O.depth_from_disp16(d16, Q)
+    assert np.array_equal(depth, want) and (depth > 0).mean() > 0.2

@@ -242,3 +242,54 @@ def test_simple_extractor_fill_equals_unreachable_from_outside(O):
         assert not (fin & ~filled).any()
         # and every component holding a 3x3 block has positive contour area, so it is kept
         assert (fin[1:-1, 1:-1] >= (masks[1] > 0)).all()
+
+
+def test_remap_known_answers(O):
+    """cv2.remap semantics: identity map is the identity; half-pixel shifts average neighbours with
+    round-half-up of the 15-bit fixed point; map fractions are quantised to 1/32 px (round half to even);
+    taps outside the image read 0."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:20, 0:30].astype(np.float32)
+    assert np.array_equal(O.remap_bilinear(img, xx, yy), img)
+    g = img[:, :, 0]
+    half = O.remap_bilinear(g, xx + 0.5, yy)
+    want = (g[:, :-1].astype(int) + g[:, 1:].astype(int) + 1) >> 1
+    assert np.array_equal(half[:, :-1], want)
+    assert np.array_equal(half[:, -1], (g[:, -1].astype(int) + 1) >> 1)          # right tap is outside: 0
+    # 1/64 px rounds to 0/32 (half to even), 3/64 px to 2/32
+    assert np.array_equal(O.remap_bilinear(g, xx + 1 / 64, yy), g)
+    q = O.remap_bilinear(g, xx + 3 / 64, yy)
+    want = (g[:, :-1].astype(int) * 30 * 32 * 32 + g[:, 1:].astype(int) * 2 * 32 * 32 + (1 << 14)) >> 15
+    assert np.array_equal(q[:, :-1], want)
+    # far outside and NaN: constant 0; negative fractional coordinates use floor semantics
+    far = O.remap_bilinear(g, np.full_like(xx, 1e9), yy)
+    assert (far == 0).all() and (O.remap_bilinear(g, np.full_like(xx, np.nan), yy) == 0).all()
+    neg = O.remap_bilinear(g, xx - 0.25, yy)
+    assert np.array_equal(neg[:, 0], (g[:, 0].astype(int) * 24 * 32 * 32 + (1 << 14)) >> 15)
+    # vertical direction and a different destination size
+    sub = O.remap_bilinear(img, xx[:7, :9] + 3, yy[:7, :9] + 2.5)
+    want = (img[2:9, 3:12].astype(int) + img[3:10, 3:12].astype(int) + 1) >> 1
+    assert np.array_equal(sub, want)
+
+
+def test_init_undistort_rectify_map_properties(O):
+    K = np.array([[300.0, 0, 160], [0, 305.0, 120], [0, 0, 1]])
+    # no distortion, same camera: identity map
+    mx, my = O.init_undistort_rectify_map(K, np.zeros(5), np.eye(3), K, (320, 240))
+    yy, xx = np.mgrid[0:240, 0:320]
+    assert np.abs(mx - xx).max() < 1e-3 and np.abs(my - yy).max() < 1e-3
+    # new camera with another principal point / focal length: the pinhole relation
+    P = np.array([[150.0, 0, 100, 0], [0, 150.0, 80, 0], [0, 0, 1, 0]])
+    mx, my = O.init_undistort_rectify_map(K, None if False else np.zeros(4), np.eye(3), P, (200, 160))
+    yy, xx = np.mgrid[0:160, 0:200]
+    assert np.abs(mx - ((xx - 100) / 150 * 300 + 160)).max() < 1e-3 and np.abs(my - ((yy - 80) / 150 * 305 + 120)).max() < 1e-3
+    # radial distortion: the map is the forward model of the normalised point
+    dist = np.array([-0.1, 0.02, 1e-3, -2e-3, 0.005])
+    mx, my = O.init_undistort_rectify_map(K, dist, np.eye(3), K, (320, 240))
+    x, y = (xx[:240, :320] if False else np.mgrid[0:240, 0:320][1] - 160) / 300, (np.mgrid[0:240, 0:320][0] - 120) / 305
+    r2 = x * x + y * y
+    kr = 1 + ((dist[4] * r2 + dist[1]) * r2 + dist[0]) * r2
+    xd = x * kr + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * kr + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    assert np.abs(mx - (xd * 300 + 160)).max() < 1e-3 and np.abs(my - (yd * 305 + 120)).max() < 1e-3
