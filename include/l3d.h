@@ -212,6 +212,33 @@ int l3d_simple_extract_device(l3d_simple *h, const uint8_t *d_bgr, int width, in
                               double min_area, double *xy, int *count, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Steger variants (improved_steger.py).  Points are float32 (x, y) pairs.
+ * ------------------------------------------------------------------------- */
+/* replaces ImprovedStegerExtractor.__init__ (improved_steger.py:18-37); also the
+ * Steger stage of HybridLaserExtractor (sigma only, :232-248) */
+int l3d_steger_create_improved(double sigma, int brightness_threshold, double response_threshold,
+                               int max_width, int max_height, int max_batch, int device, l3d_steger **out);
+/* replaces ImprovedStegerExtractor.extract_centerline (per_row = 0, improved_steger.py:39-126:
+ * every accepted pixel, raster order) and .extract_centerline_optimized (per_row = 1,
+ * :128-223: per image row the accepted pixel with the largest |eigenvalue|, y = row).
+ * Same argument meaning as l3d_steger_extract, without a ROI. */
+int l3d_steger_extract_improved(l3d_steger *h, const uint8_t *img, int channels, int width, int height,
+                                int batch, int per_row, float *xy, int capacity, int *counts);
+int l3d_steger_extract_improved_device(l3d_steger *h, const uint8_t *d_img, int channels, int width, int height,
+                                       int batch, int per_row, float *d_xy, int capacity, int *d_counts,
+                                       void *stream);
+/* replaces HybridLaserExtractor.extract_centerline (improved_steger.py:250-344): HSV +
+ * brightness mask, 3x3 close and open (run by `mask_maker`), image zeroed outside the
+ * mask, Steger per row on the mask's pixels with |offset_x| <= 0.5.  One BGR image;
+ * mask (may be NULL) receives the cleaned mask [height][width]. */
+int l3d_hybrid_extract(l3d_simple *mask_maker, l3d_steger *h, const uint8_t *bgr, int width, int height,
+                       const int *hsv_lower, const int *hsv_upper, int brightness_threshold, float *xy,
+                       int capacity, int *count, uint8_t *mask);
+int l3d_hybrid_extract_device(l3d_simple *mask_maker, l3d_steger *h, const uint8_t *d_bgr, int width, int height,
+                              const int *hsv_lower, const int *hsv_upper, int brightness_threshold,
+                              float *d_xy, int capacity, int *d_count, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Stereo rectification: maps and bilinear remap.
  * ------------------------------------------------------------------------- */
 typedef struct l3d_remap l3d_remap;

@@ -109,6 +109,11 @@ def _load():
         "l3d_simple_destroy": (None, [vp]),
         "l3d_simple_extract": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
         "l3d_simple_extract_device": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
+        "l3d_steger_create_improved": (i, [C.c_double, i, C.c_double, i, i, i, i, C.POINTER(vp)]),
+        "l3d_steger_extract_improved": (i, [vp, vp, i, i, i, i, i, vp, i, vp]),
+        "l3d_steger_extract_improved_device": (i, [vp, vp, i, i, i, i, i, vp, i, vp, vp]),
+        "l3d_hybrid_extract": (i, [vp, vp, vp, i, i, pi, pi, i, vp, i, pi, vp]),
+        "l3d_hybrid_extract_device": (i, [vp, vp, vp, i, i, pi, pi, i, vp, i, vp, vp]),
         "l3d_remap_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
         "l3d_remap_create_rectify": (i, [vp, vp, i, vp, i, i, i, C.POINTER(vp)]),
         "l3d_remap_destroy": (None, [vp]),

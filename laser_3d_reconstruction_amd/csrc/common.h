@@ -47,3 +47,12 @@ struct DeviceGuard {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 } // namespace l3d
+
+// Colour + brightness mask after the 3x3 close and open (stages shared by SimpleLaserExtractor and
+// HybridLaserExtractor); *d_mask points into the handle and stays valid until its next use.  Defined in simple.hip.
+int simple_clean_mask(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const int *lo, const int *hi, int thr, hipStream_t s,
+                      const uint8_t **d_mask);
+
+namespace l3d {
+
+} // namespace l3d

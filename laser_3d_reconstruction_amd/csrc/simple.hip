@@ -294,6 +294,26 @@ extern "C" int l3d_simple_create(int max_width, int max_height, int device, l3d_
     return L3D_OK;
 }
 
+int simple_clean_mask(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const int *lo, const int *hi, int thr, hipStream_t s,
+                      const uint8_t **d_mask)
+{
+    L3D_REQUIRE(h && W > 0 && H > 0 && W <= h->max_w && H <= h->max_h && (size_t)W * H <= (size_t)h->max_w * h->max_h,
+                "clean mask: image %dx%d exceeds the handle's %dx%d", W, H, h ? h->max_w : 0, h ? h->max_h : 0);
+    const int n = W * H;
+    HsvRange r;
+    for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; }
+    r.thr = thr;
+    const dim3 g1(cdiv(n, 256)), g2(cdiv(W, 256), H), b(256);
+    hipLaunchKernelGGL(k_simple_mask, g1, b, 0, s, d_bgr, n, r, h->sdiv, h->hdiv, h->gray, h->m0);
+    hipLaunchKernelGGL(k_morph3, g2, b, 0, s, h->m0, W, H, 1, h->m1); // close = erode(dilate)
+    hipLaunchKernelGGL(k_morph3, g2, b, 0, s, h->m1, W, H, 0, h->m0);
+    hipLaunchKernelGGL(k_morph3, g2, b, 0, s, h->m0, W, H, 0, h->m1); // open = dilate(erode)
+    hipLaunchKernelGGL(k_morph3, g2, b, 0, s, h->m1, W, H, 1, h->m0);
+    L3D_HIP_CHECK(hipGetLastError());
+    *d_mask = h->m0;
+    return L3D_OK;
+}
+
 static int simple_run(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const int *lo, const int *hi, int thr, double min_area, double *xy,
                       int *count, uint8_t *masks, hipStream_t s)
 {

@@ -14,6 +14,12 @@
 // A second kernel turns the cell counts into raster-order offsets (one block per image) and
 // copies the points into the dense output, so the result has the order of the reference's
 // `for j: for i:` loop.
+//
+// The same tile kernel, as template variants, serves ImprovedStegerExtractor.extract_centerline,
+// .extract_centerline_optimized and HybridLaserExtractor.extract_centerline (improved_steger.py:39-126,
+// 128-223, 250-344): Sobel-of-Sobel derivatives (blurred halo of 2), a negative-eigenvalue test, and for
+// the last two one point per image row, the accepted pixel with the largest |eigenvalue| (wave arg-max in
+// the tile, then a per-row pass over the row's tiles).
 #include "common.h"
 #include <cmath>
 #include <new>
@@ -31,7 +37,14 @@ struct StegerArgs {
     int R;                // kernel radius (ksize = 2R+1)
     int thr;
     int ntx, nty;         // tiles per region
+    double resp_thr;      // largest accepted |offset| of the improved variants
 };
+
+// kernel variants
+constexpr int VAR_FAST = 0;      // FastStegerExtractor: every accepted pixel
+constexpr int VAR_IMPROVED = 1;  // ImprovedStegerExtractor.extract_centerline: every accepted pixel
+constexpr int VAR_PER_ROW = 2;   // ... .extract_centerline_optimized: best pixel per row
+constexpr int VAR_HYBRID = 3;    // HybridLaserExtractor: best pixel per row among the pixels of a mask
 
 __device__ __forceinline__ int reflect101(int p, int n)
 {
@@ -76,14 +89,50 @@ __device__ __forceinline__ bool steger_point(float dx, float dy, float dxx, floa
     return false;
 }
 
+// Decision of the improved variants.  The Hessian entries are float as in the reference; its eigenpair comes
+// from the closed form in double and is rounded to float (np.linalg.eig of a float32 matrix returns float32);
+// the remaining scalar arithmetic follows NumPy < 2.0: float32 * float32 stays float32, a Python number times
+// a float32 scalar is float64.  Returns false when the reference `continue`s; lam = the eigenvalue.
+__device__ __forceinline__ bool steger2_point(float dx, float dy, float dxx, float dyy, float dxy, float &lamf, double &ox, double &oy)
+{
+    const double a = dxx, b = dxy, c = dyy;
+    double lam, nx, ny;
+    if (b == 0.0) {
+        if (fabs(a) >= fabs(c)) { lam = a; nx = 1.0; ny = 0.0; }
+        else { lam = c; nx = 0.0; ny = 1.0; }
+    } else {
+        const double m = 0.5 * (a + c), hd = 0.5 * (a - c);
+        const double rr = sqrt(hd * hd + b * b);
+        lam = (m >= 0.0) ? m + rr : m - rr;
+        const double v1x = b, v1y = lam - a, v2x = lam - c, v2y = b;
+        const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y;
+        if (n1 >= n2) { const double s = 1.0 / sqrt(n1); nx = v1x * s; ny = v1y * s; }
+        else { const double s = 1.0 / sqrt(n2); nx = v2x * s; ny = v2y * s; }
+    }
+    lamf = (float)lam;
+    const float nxf = (float)nx, nyf = (float)ny;
+    if (lamf >= 0.0f) return false;
+    const float t1 = (nxf * nxf) * dxx, t3 = (nyf * nyf) * dyy;
+    const double t2 = ((2.0 * (double)nxf) * (double)nyf) * (double)dxy;
+    const double den = ((double)t1 + t2) + (double)t3;
+    if (fabs(den) < 1e-6) return false;
+    const float num = -(nxf * dx + nyf * dy);
+    const double t = (double)num / den;
+    ox = t * (double)nxf;
+    oy = t * (double)nyf;
+    return true;
+}
+
 // grid: (ntx, nty, batch); block 256 = 4 waves; wave w handles tile rows w, w+4, w+8, w+12
-__global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t *__restrict__ img, const float *__restrict__ taps,
-                                                     float2 *__restrict__ cells, int *__restrict__ cell_counts)
+template <int VAR>
+__global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                     const float *__restrict__ taps, float2 *__restrict__ cells, int *__restrict__ cell_counts)
 {
     extern __shared__ float sm[];
+    constexpr int HB = VAR == VAR_FAST ? 1 : 2;         // halo of the blurred tile that the derivative stencils reach
     const int R = a.R, ks = 2 * R + 1;
-    const int GW = TW + 2 + 2 * R, GH = TH + 2 + 2 * R; // gray tile incl. halo
-    const int BW = TW + 2, BH = TH + 2;                 // blurred tile (+-1 for the stencils)
+    const int GW = TW + 2 * HB + 2 * R, GH = TH + 2 * HB + 2 * R; // gray tile incl. halo
+    const int BW = TW + 2 * HB, BH = TH + 2 * HB;                 // blurred tile
     float *gt = sm;                 // [GH][GW]
     float *hrow = gt + GH * GW;     // [GH][BW]
     float *bl = hrow + GH * BW;     // [BH][BW]
@@ -93,7 +142,13 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
     const uint8_t *im = img + (size_t)b * a.W * a.H * a.channels;
+    const uint8_t *mk = VAR == VAR_HYBRID ? mask + (size_t)b * a.W * a.H : nullptr;
     const size_t cell_base = ((size_t)b * a.rh) * a.ntx;
+    // value that is blurred: the gray image; for the hybrid variant the gray image zeroed outside the mask
+    auto src_at = [&](int x, int y) -> int {
+        if (VAR == VAR_HYBRID && !mk[(size_t)y * a.W + x]) return 0;
+        return gray_at(im, a, x, y);
+    };
 
     if (tid == 0) any_bright = 0;
     __syncthreads();
@@ -103,7 +158,9 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x = tx0 + lane, y = ty0 + wv + 4 * k;
-        own[k] = (x < a.rw && y < a.rh) ? gray_at(im, a, x, y) : -1;
+        const bool inside = VAR == VAR_FAST ? (x < a.rw && y < a.rh) : (x >= 1 && x < a.rw - 1 && y >= 1 && y < a.rh - 1);
+        if (VAR == VAR_HYBRID) own[k] = (inside && mk[(size_t)y * a.W + x]) ? a.thr + 1 : -1;
+        else own[k] = inside ? gray_at(im, a, x, y) : -1;
         bright |= own[k] > a.thr;
     }
     if (__ballot(bright) != 0ull && lane == 0) any_bright = 1;
@@ -123,8 +180,8 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     // gray tile with halo; coordinates outside the region are mirrored (BORDER_REFLECT_101)
     for (int i = tid; i < GH * GW; i += 256) {
         const int gy = i / GW, gx = i - gy * GW;
-        const int x = reflect101(tx0 - 1 - R + gx, a.rw), y = reflect101(ty0 - 1 - R + gy, a.rh);
-        gt[i] = (float)gray_at(im, a, x, y);
+        const int x = reflect101(tx0 - HB - R + gx, a.rw), y = reflect101(ty0 - HB - R + gy, a.rh);
+        gt[i] = (float)src_at(x, y);
     }
     __syncthreads();
     // row pass: taps accumulated left to right
@@ -149,7 +206,7 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     // blurred value at region coordinates (x, y), mirrored at the region border
     auto B = [&](int x, int y) -> float {
         const int xr = reflect101(x, a.rw), yr = reflect101(y, a.rh);
-        return bl[(yr - ty0 + 1) * BW + (xr - tx0 + 1)];
+        return bl[(yr - ty0 + HB) * BW + (xr - tx0 + HB)];
     };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -157,22 +214,97 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         if (y >= a.rh) continue; // wave-uniform
         bool acc = false;
         double ox = 0.0, oy = 0.0;
+        float resp = 0.0f;
         if (own[k] > a.thr) {
-            const float c = B(x, y), l = B(x - 1, y), r = B(x + 1, y), u = B(x, y - 1), d = B(x, y + 1), ul = B(x - 1, y - 1);
-            const float dx = l - c;
-            const float dy = u - c;
-            const float dxx = (l + (-2.0f * c)) + r;
-            const float dyy = (u + (-2.0f * c)) + d;
-            const float dxy = ((ul - u) - l) + c;
-            acc = steger_point(dx, dy, dxx, dyy, dxy, ox, oy);
+            if (VAR == VAR_FAST) {
+                const float c = B(x, y), l = B(x - 1, y), r = B(x + 1, y), u = B(x, y - 1), d = B(x, y + 1), ul = B(x - 1, y - 1);
+                const float dx = l - c;
+                const float dy = u - c;
+                const float dxx = (l + (-2.0f * c)) + r;
+                const float dyy = (u + (-2.0f * c)) + d;
+                const float dxy = ((ul - u) - l) + c;
+                acc = steger_point(dx, dy, dxx, dyy, dxy, ox, oy);
+            } else {
+                // Sobel (ksize 3) of the blurred image at the 3x3 neighbourhood, then Sobel of those: 3-tap
+                // passes along x first, then along y, summed as (a + c) + 2b
+                float rd[5][3], rs[5][3]; // x-difference and x-smoothing of the blurred rows y-2..y+2 at columns x-1..x+1
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const float l = B(x + i - 2, y + j - 2), c = B(x + i - 1, y + j - 2), r = B(x + i, y + j - 2);
+                        rd[j][i] = r - l;
+                        rs[j][i] = (l + r) + c * 2.0f;
+                    }
+                float gx[3][3], gy[3][3]; // dx and dy images at rows y-1..y+1, columns x-1..x+1
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        gx[j][i] = (rd[j][i] + rd[j + 2][i]) + rd[j + 1][i] * 2.0f;
+                        gy[j][i] = rs[j + 2][i] - rs[j][i];
+                    }
+                const float dx = gx[1][1], dy = gy[1][1];
+                const float dxx = ((gx[0][2] - gx[0][0]) + (gx[2][2] - gx[2][0])) + (gx[1][2] - gx[1][0]) * 2.0f;
+                const float dyy = ((gy[2][0] + gy[2][2]) + gy[2][1] * 2.0f) - ((gy[0][0] + gy[0][2]) + gy[0][1] * 2.0f);
+                const float dxy = ((gx[2][0] + gx[2][2]) + gx[2][1] * 2.0f) - ((gx[0][0] + gx[0][2]) + gx[0][1] * 2.0f);
+                float lam;
+                if (steger2_point(dx, dy, dxx, dyy, dxy, lam, ox, oy)) {
+                    resp = fabsf(lam);
+                    if (VAR == VAR_HYBRID) acc = fabs(ox) <= 0.5;
+                    else acc = fabs(ox) <= a.resp_thr && fabs(oy) <= a.resp_thr;
+                    if (VAR == VAR_IMPROVED && acc) {
+                        const double cx = (double)x + ox, cy = (double)y + oy;
+                        acc = 0 <= cx && cx < a.W && 0 <= cy && cy < a.H;
+                    }
+                }
+            }
         }
         const unsigned long long m = __ballot(acc);
         const size_t cell = cell_base + (size_t)y * a.ntx + blockIdx.x;
-        if (acc) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            cells[cell * TW + rank] = make_float2((float)((double)x + ox + (double)a.x0), (float)((double)y + oy + (double)a.y0));
+        if (VAR == VAR_FAST || VAR == VAR_IMPROVED) {
+            if (acc) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                cells[cell * TW + rank] = make_float2((float)((double)x + ox + (double)a.x0), (float)((double)y + oy + (double)a.y0));
+            }
+            if (lane == 0) cell_counts[cell] = __popcll(m);
+        } else {
+            // largest response of the tile row, leftmost pixel on ties: max over (response bits, 63 - lane)
+            unsigned long long key = acc ? (((unsigned long long)__float_as_uint(resp) << 8) | (unsigned long long)(63 - lane)) : 0ull;
+            unsigned long long best = key;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const unsigned long long other = __shfl_xor(best, o);
+                best = other > best ? other : best;
+            }
+            if (acc && key == best) {
+                const double bx = (double)x + ox;
+                // the reference drops a row whose best point leaves the image: flagged by a NaN x
+                cells[cell * TW] = make_float2((0 <= bx && bx < a.W) ? (float)bx : __builtin_nanf(""), resp);
+            }
+            if (lane == 0) cell_counts[cell] = m != 0ull;
         }
-        if (lane == 0) cell_counts[cell] = __popcll(m);
+    }
+}
+
+// per-row variants: the best candidate over the tiles of a row (first tile on ties) becomes the row's only point
+__global__ void __launch_bounds__(256) k_steger_rowbest(int nrows_total, int rh, int ntx, float2 *__restrict__ cells, int *__restrict__ cell_counts)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x; // over batch * rh
+    if (row >= nrows_total) return;
+    const size_t c0 = (size_t)row * ntx;
+    float best_resp = -1.0f, best_x = 0.0f;
+    bool have = false;
+    for (int t = 0; t < ntx; t++) {
+        if (cell_counts[c0 + t]) {
+            const float2 v = cells[(c0 + t) * TW];
+            if (v.y > best_resp) { best_resp = v.y; best_x = v.x; have = true; }
+        }
+        cell_counts[c0 + t] = 0;
+    }
+    if (have && best_x == best_x) {
+        cells[c0 * TW] = make_float2(best_x, (float)(row % rh));
+        cell_counts[c0] = 1;
     }
 }
 
@@ -221,8 +353,9 @@ using namespace l3d;
 
 struct l3d_steger {
     int device = 0, max_w = 0, max_h = 0, max_batch = 0;
-    double sigma = 3.0;
+    double sigma = 3.0, resp_thr = 0.5;
     int thr = 200, R = 12;
+    bool improved = false; // built by l3d_steger_create_improved: serves the improved / hybrid variants
     hipStream_t stream = nullptr;
     float *taps = nullptr;
     float2 *cells = nullptr;
@@ -246,8 +379,25 @@ extern "C" void l3d_steger_destroy(l3d_steger *h)
     delete h;
 }
 
+static int steger_create(double sigma, int brightness_threshold, int max_width, int max_height, int max_batch, int device, l3d_steger **out);
+
 extern "C" int l3d_steger_create(double sigma, int brightness_threshold, int max_width, int max_height, int max_batch, int device,
                                  l3d_steger **out)
+{
+    return steger_create(sigma, brightness_threshold, max_width, max_height, max_batch, device, out);
+}
+
+extern "C" int l3d_steger_create_improved(double sigma, int brightness_threshold, double response_threshold, int max_width, int max_height,
+                                          int max_batch, int device, l3d_steger **out)
+{
+    const int rc = steger_create(sigma, brightness_threshold, max_width, max_height, max_batch, device, out);
+    if (rc) return rc;
+    (*out)->improved = true;
+    (*out)->resp_thr = response_threshold;
+    return L3D_OK;
+}
+
+static int steger_create(double sigma, int brightness_threshold, int max_width, int max_height, int max_batch, int device, l3d_steger **out)
 {
     L3D_REQUIRE(out, "l3d_steger_create: null argument");
     *out = nullptr;
@@ -304,7 +454,7 @@ extern "C" int l3d_steger_create(double sigma, int brightness_threshold, int max
 }
 
 static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, int H, int B, const int *roi, float *d_xy, int capacity,
-                      int *d_counts, hipStream_t s)
+                      int *d_counts, hipStream_t s, int variant = VAR_FAST, const uint8_t *d_mask = nullptr)
 {
     StegerArgs a;
     a.W = W; a.H = H; a.channels = channels;
@@ -316,17 +466,25 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
         a.rw = std::max(0, std::min(W, roi[0] + roi[2]) - a.x0);
         a.rh = std::max(0, std::min(H, roi[1] + roi[3]) - a.y0);
     }
-    a.R = h->R; a.thr = h->thr;
+    a.R = h->R; a.thr = h->thr; a.resp_thr = h->resp_thr;
     a.ntx = cdiv(std::max(a.rw, 1), TW);
     a.nty = cdiv(std::max(a.rh, 1), TH);
     if (a.rw <= 0 || a.rh <= 0) {
         L3D_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), s));
         return L3D_OK;
     }
-    const int R = a.R;
-    const size_t lds = ((size_t)(TH + 2 + 2 * R) * (TW + 2 + 2 * R) + (size_t)(TH + 2 + 2 * R) * (TW + 2) + (size_t)(TH + 2) * (TW + 2) +
-                        (2 * R + 1) + 1) * sizeof(float);
-    hipLaunchKernelGGL(k_steger_tile, dim3(a.ntx, a.nty, B), dim3(256), lds, s, a, d_img, h->taps, h->cells, h->cell_counts);
+    const int R = a.R, HB = variant == VAR_FAST ? 1 : 2;
+    const size_t lds = ((size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB + 2 * R) + (size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB) +
+                        (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 1) * sizeof(float);
+    const dim3 grid(a.ntx, a.nty, B);
+    switch (variant) {
+    case VAR_FAST: hipLaunchKernelGGL(k_steger_tile<VAR_FAST>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
+    case VAR_IMPROVED: hipLaunchKernelGGL(k_steger_tile<VAR_IMPROVED>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
+    case VAR_PER_ROW: hipLaunchKernelGGL(k_steger_tile<VAR_PER_ROW>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
+    default: hipLaunchKernelGGL(k_steger_tile<VAR_HYBRID>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
+    }
+    if (variant == VAR_PER_ROW || variant == VAR_HYBRID)
+        hipLaunchKernelGGL(k_steger_rowbest, dim3(cdiv(B * a.rh, 256)), dim3(256), 0, s, B * a.rh, a.rh, a.ntx, h->cells, h->cell_counts);
     const int ncells = a.rh * a.ntx;
     hipLaunchKernelGGL(k_steger_compact, dim3(B), dim3(1024), 0, s, ncells, h->cells, h->cell_counts, h->cell_offsets, (float2 *)d_xy,
                        capacity, d_counts);
@@ -355,18 +513,19 @@ extern "C" int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, in
     return steger_run(h, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, (hipStream_t)stream);
 }
 
-extern "C" int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, const int *roi,
-                                  float *xy, int capacity, int *counts)
+// host images in, points out, through the handle's staging buffers
+static int steger_host(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, const int *roi, float *xy, int capacity,
+                       int *counts, int variant, const char *who)
 {
-    int rc = steger_check(h, channels, width, height, batch, capacity, "l3d_steger_extract");
+    int rc = steger_check(h, channels, width, height, batch, capacity, who);
     if (rc) return rc;
-    L3D_REQUIRE(img && xy && counts, "l3d_steger_extract: null argument");
+    L3D_REQUIRE(img && xy && counts, "%s: null argument", who);
     DeviceGuard dg(h->device);
     hipStream_t s = h->stream;
     const size_t px = (size_t)width * height;
     const int cap_dev = (int)std::min<size_t>((size_t)capacity, px);
     L3D_HIP_CHECK(hipMemcpyAsync(h->in, img, px * channels * batch, hipMemcpyHostToDevice, s));
-    rc = steger_run(h, h->in, channels, width, height, batch, roi, (float *)h->out, cap_dev, h->counts, s);
+    rc = steger_run(h, h->in, channels, width, height, batch, roi, (float *)h->out, cap_dev, h->counts, s, variant);
     if (rc) return rc;
     L3D_HIP_CHECK(hipMemcpyAsync(counts, h->counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, s));
     L3D_HIP_CHECK(hipStreamSynchronize(s));
@@ -377,7 +536,76 @@ extern "C" int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channel
         if (n > 0) L3D_HIP_CHECK(hipMemcpy(xy + (size_t)b * capacity * 2, h->out + (size_t)b * cap_dev, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
     }
     if (overflow) {
-        set_error("l3d_steger_extract: more points than capacity %d", capacity);
+        set_error("%s: more points than capacity %d", who, capacity);
+        return L3D_ERR_CAPACITY;
+    }
+    return L3D_OK;
+}
+
+extern "C" int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, const int *roi,
+                                  float *xy, int capacity, int *counts)
+{
+    return steger_host(h, img, channels, width, height, batch, roi, xy, capacity, counts, VAR_FAST, "l3d_steger_extract");
+}
+
+extern "C" int l3d_steger_extract_improved(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch, int per_row,
+                                           float *xy, int capacity, int *counts)
+{
+    L3D_REQUIRE(h && h->improved, "l3d_steger_extract_improved: the handle was not made by l3d_steger_create_improved");
+    return steger_host(h, img, channels, width, height, batch, nullptr, xy, capacity, counts, per_row ? VAR_PER_ROW : VAR_IMPROVED,
+                       "l3d_steger_extract_improved");
+}
+
+extern "C" int l3d_steger_extract_improved_device(l3d_steger *h, const uint8_t *d_img, int channels, int width, int height, int batch, int per_row,
+                                                  float *d_xy, int capacity, int *d_counts, void *stream)
+{
+    L3D_REQUIRE(h && h->improved, "l3d_steger_extract_improved_device: the handle was not made by l3d_steger_create_improved");
+    int rc = steger_check(h, channels, width, height, batch, capacity, "l3d_steger_extract_improved_device");
+    if (rc) return rc;
+    L3D_REQUIRE(d_img && d_xy && d_counts, "l3d_steger_extract_improved_device: null argument");
+    DeviceGuard dg(h->device);
+    return steger_run(h, d_img, channels, width, height, batch, nullptr, d_xy, capacity, d_counts, (hipStream_t)stream,
+                      per_row ? VAR_PER_ROW : VAR_IMPROVED);
+}
+
+extern "C" int l3d_hybrid_extract_device(l3d_simple *mask_maker, l3d_steger *h, const uint8_t *d_bgr, int width, int height, const int *hsv_lower,
+                                         const int *hsv_upper, int brightness_threshold, float *d_xy, int capacity, int *d_count, void *stream)
+{
+    L3D_REQUIRE(mask_maker && h && h->improved, "l3d_hybrid_extract_device: needs a l3d_simple handle and a handle made by l3d_steger_create_improved");
+    int rc = steger_check(h, 3, width, height, 1, capacity, "l3d_hybrid_extract_device");
+    if (rc) return rc;
+    L3D_REQUIRE(d_bgr && hsv_lower && hsv_upper && d_xy && d_count, "l3d_hybrid_extract_device: null argument");
+    DeviceGuard dg(h->device);
+    const uint8_t *d_mask = nullptr;
+    rc = simple_clean_mask(mask_maker, d_bgr, width, height, hsv_lower, hsv_upper, brightness_threshold, (hipStream_t)stream, &d_mask);
+    if (rc) return rc;
+    return steger_run(h, d_bgr, 3, width, height, 1, nullptr, d_xy, capacity, d_count, (hipStream_t)stream, VAR_HYBRID, d_mask);
+}
+
+extern "C" int l3d_hybrid_extract(l3d_simple *mask_maker, l3d_steger *h, const uint8_t *bgr, int width, int height, const int *hsv_lower,
+                                  const int *hsv_upper, int brightness_threshold, float *xy, int capacity, int *count, uint8_t *mask)
+{
+    L3D_REQUIRE(mask_maker && h && h->improved, "l3d_hybrid_extract: needs a l3d_simple handle and a handle made by l3d_steger_create_improved");
+    int rc = steger_check(h, 3, width, height, 1, capacity, "l3d_hybrid_extract");
+    if (rc) return rc;
+    L3D_REQUIRE(bgr && hsv_lower && hsv_upper && xy && count, "l3d_hybrid_extract: null argument");
+    DeviceGuard dg(h->device);
+    hipStream_t s = h->stream;
+    const size_t px = (size_t)width * height;
+    const int cap_dev = (int)std::min<size_t>((size_t)capacity, px);
+    L3D_HIP_CHECK(hipMemcpyAsync(h->in, bgr, px * 3, hipMemcpyHostToDevice, s));
+    const uint8_t *d_mask = nullptr;
+    rc = simple_clean_mask(mask_maker, h->in, width, height, hsv_lower, hsv_upper, brightness_threshold, s, &d_mask);
+    if (rc) return rc;
+    rc = steger_run(h, h->in, 3, width, height, 1, nullptr, (float *)h->out, cap_dev, h->counts, s, VAR_HYBRID, d_mask);
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipMemcpyAsync(count, h->counts, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (mask) L3D_HIP_CHECK(hipMemcpyAsync(mask, d_mask, px, hipMemcpyDeviceToHost, s));
+    L3D_HIP_CHECK(hipStreamSynchronize(s));
+    const int n = std::min(*count, cap_dev);
+    if (n > 0) L3D_HIP_CHECK(hipMemcpy(xy, h->out, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    if (*count > capacity) {
+        set_error("l3d_hybrid_extract: more points than capacity %d", capacity);
         return L3D_ERR_CAPACITY;
     }
     return L3D_OK;

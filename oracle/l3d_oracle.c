@@ -1214,3 +1214,163 @@ ORC_API void orc_remap_bilinear_u8(const uint8_t *src, int sw, int sh, int ch, c
         }
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Steger variants (improved_steger.py:39-126, 128-223, 250-344): float      */
+/* GaussianBlur, Sobel (ksize 3) of Sobel for the second derivatives, the    */
+/* eigenvector of the larger |eigenvalue| kept only when that eigenvalue is  */
+/* negative (bright line).  Parity unpinned (OpenCV's float summation order  */
+/* in Sobel and LAPACK's float32 eigenvectors are restated, not observed).   */
+/* The scalar arithmetic after the Hessian follows NumPy < 2.0 (the          */
+/* reference's requirement): float32 * float32 stays float32, a Python       */
+/* number times a float32 scalar becomes float64.                            */
+/* ------------------------------------------------------------------------ */
+typedef struct { int ok; float lam; double ox, oy; } steger2_res;
+
+static steger2_res steger2_point(float dx, float dy, float dxx, float dyy, float dxy)
+{
+    steger2_res r = {0, 0.0f, 0.0, 0.0};
+    const double a = dxx, b = dxy, c = dyy;
+    double lam, nx, ny;
+    if (b == 0.0) {
+        if (fabs(a) >= fabs(c)) { lam = a; nx = 1.0; ny = 0.0; }
+        else { lam = c; nx = 0.0; ny = 1.0; }
+    } else {
+        const double m = 0.5 * (a + c), hd = 0.5 * (a - c);
+        const double rr = sqrt(hd * hd + b * b);
+        lam = (m >= 0.0) ? m + rr : m - rr;
+        const double v1x = b, v1y = lam - a, v2x = lam - c, v2y = b;
+        const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y;
+        if (n1 >= n2) { const double s = 1.0 / sqrt(n1); nx = v1x * s; ny = v1y * s; }
+        else { const double s = 1.0 / sqrt(n2); nx = v2x * s; ny = v2y * s; }
+    }
+    const float lamf = (float)lam, nxf = (float)nx, nyf = (float)ny;
+    if (lamf >= 0.0f) return r;
+    const float t1 = (nxf * nxf) * dxx, t3 = (nyf * nyf) * dyy;
+    const double t2 = ((2.0 * (double)nxf) * (double)nyf) * (double)dxy;
+    const double den = ((double)t1 + t2) + (double)t3;
+    if (fabs(den) < 1e-6) return r;
+    const float num = -(nxf * dx + nyf * dy);
+    const double t = (double)num / den;
+    r.ok = 1; r.lam = lamf; r.ox = t * (double)nxf; r.oy = t * (double)nyf;
+    return r;
+}
+
+/* the five derivative planes of the reference: dx, dy = Sobel of the blurred image, dxx = Sobel_x(dx),
+ * dyy = Sobel_y(dy), dxy = Sobel_y(dx); 3-tap passes summed as (a + c) + 2b, BORDER_REFLECT_101 */
+static void sobel3_f32(const float *src, int W, int H, int xorder, float *tmp, float *dst)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float l = src[(size_t)y * W + reflect101(x - 1, W)], c = src[(size_t)y * W + x], r = src[(size_t)y * W + reflect101(x + 1, W)];
+            tmp[(size_t)y * W + x] = xorder ? r - l : (l + r) + c * 2.0f;
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float u = tmp[(size_t)reflect101(y - 1, H) * W + x], c = tmp[(size_t)y * W + x], d = tmp[(size_t)reflect101(y + 1, H) * W + x];
+            dst[(size_t)y * W + x] = xorder ? (u + d) + c * 2.0f : d - u;
+        }
+}
+
+/* variant 1: every accepted pixel (raster order); variant 2: the accepted pixel of largest |eigenvalue| per row
+ * (first one on ties), y = row; variant 3: as 2 but only |offset_x| <= 0.5 is tested and candidates are the
+ * pixels of `mask`.  gray8: brightness image (test gray8 > threshold; ignored when mask is given).
+ * src: image that is blurred (float of the gray image).  xy: doubles. */
+static int steger2_core(const uint8_t *gray8, const uint8_t *mask, const float *src, int W, int H, double sigma, int threshold,
+                        double resp_thr, int variant, double *xy, int capacity, int *count)
+{
+    float taps[512];
+    int ks = orc_gauss_kernel(sigma, taps, 512);
+    if (ks < 0) return -3;
+    const size_t n = (size_t)W * H;
+    float *bl = (float *)malloc(n * sizeof(float)), *tmp = (float *)malloc(n * sizeof(float));
+    float *dx = (float *)malloc(n * sizeof(float)), *dy = (float *)malloc(n * sizeof(float));
+    float *dxx = (float *)malloc(n * sizeof(float)), *dyy = (float *)malloc(n * sizeof(float)), *dxy = (float *)malloc(n * sizeof(float));
+    gauss_blur_f32(src, W, H, taps, ks, bl);
+    sobel3_f32(bl, W, H, 1, tmp, dx);
+    sobel3_f32(bl, W, H, 0, tmp, dy);
+    sobel3_f32(dx, W, H, 1, tmp, dxx);
+    sobel3_f32(dy, W, H, 0, tmp, dyy);
+    sobel3_f32(dx, W, H, 0, tmp, dxy);
+    int cnt = 0;
+    for (int y = 1; y < H - 1; y++) {
+        int have = 0;
+        float best_resp = -1.0f;
+        double best_x = 0.0;
+        for (int x = 1; x < W - 1; x++) {
+            const size_t o = (size_t)y * W + x;
+            if (mask ? !(mask[o] > 0) : !(gray8[o] > threshold)) continue;
+            const steger2_res r = steger2_point(dx[o], dy[o], dxx[o], dyy[o], dxy[o]);
+            if (!r.ok) continue;
+            if (variant == 1) {
+                if (fabs(r.ox) <= resp_thr && fabs(r.oy) <= resp_thr) {
+                    const double cx = (double)x + r.ox, cy = (double)y + r.oy;
+                    if (0 <= cx && cx < W && 0 <= cy && cy < H) {
+                        if (cnt < capacity) { xy[2 * cnt] = cx; xy[2 * cnt + 1] = cy; }
+                        cnt++;
+                    }
+                }
+            } else {
+                const int okk = variant == 2 ? (fabs(r.ox) <= resp_thr && fabs(r.oy) <= resp_thr) : (fabs(r.ox) <= 0.5);
+                if (okk) {
+                    const float resp = fabsf(r.lam);
+                    if (resp > best_resp) { best_resp = resp; best_x = (double)x + r.ox; have = 1; }
+                }
+            }
+        }
+        if (variant != 1 && have && 0 <= best_x && best_x < W) {
+            if (cnt < capacity) { xy[2 * cnt] = best_x; xy[2 * cnt + 1] = (double)y; }
+            cnt++;
+        }
+    }
+    *count = cnt;
+    free(bl); free(tmp); free(dx); free(dy); free(dxx); free(dyy); free(dxy);
+    return 0;
+}
+
+ORC_API int orc_steger_improved(const uint8_t *img, int channels, int W, int H, double sigma, int threshold, double resp_thr,
+                                int per_row, double *xy, int capacity, int *count)
+{
+    if (channels != 1 && channels != 3) return -1;
+    const size_t n = (size_t)W * H;
+    uint8_t *g8 = (uint8_t *)malloc(n);
+    float *gf = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *px = img + i * channels;
+        g8[i] = channels == 3 ? (uint8_t)((px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15) : px[0];
+        gf[i] = (float)g8[i];
+    }
+    const int rc = steger2_core(g8, NULL, gf, W, H, sigma, threshold, resp_thr, per_row ? 2 : 1, xy, capacity, count);
+    free(g8); free(gf);
+    return rc;
+}
+
+/* HybridLaserExtractor.extract_centerline (improved_steger.py:250-344): colour + brightness mask, 3x3 close and
+ * open, the image zeroed outside the mask, then the per-row variant on the mask's pixels.  mask_out (may be NULL)
+ * receives the cleaned mask. */
+ORC_API int orc_hybrid_extract(const uint8_t *bgr, int W, int H, const int *lower, const int *upper, int threshold, double sigma,
+                               double *xy, int capacity, int *count, uint8_t *mask_out)
+{
+    hsv_tables();
+    const size_t n = (size_t)W * H;
+    uint8_t *m0 = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n);
+    float *gf = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *px = bgr + 3 * i;
+        int hh, ss, vv;
+        bgr2hsv_px(px[0], px[1], px[2], &hh, &ss, &vv);
+        const int g = (px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15;
+        const int in = hh >= lower[0] && hh <= upper[0] && ss >= lower[1] && ss <= upper[1] && vv >= lower[2] && vv <= upper[2];
+        m0[i] = (in && g > threshold) ? 255 : 0;
+    }
+    morph3x3(m0, W, H, 1, m1); morph3x3(m1, W, H, 0, m0);
+    morph3x3(m0, W, H, 0, m1); morph3x3(m1, W, H, 1, m0);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *px = bgr + 3 * i;
+        gf[i] = m0[i] ? (float)((px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15) : 0.0f;
+    }
+    if (mask_out) memcpy(mask_out, m0, n);
+    const int rc = steger2_core(NULL, m0, gf, W, H, sigma, 0, 0.5, 3, xy, capacity, count);
+    free(m0); free(m1); free(gf);
+    return rc;
+}

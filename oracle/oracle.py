@@ -335,3 +335,35 @@ def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.
     lib().orc_remap_bilinear_u8(_p(src, C.c_uint8), sw, sh, ch, _p(mx, C.c_float), _p(my, C.c_float), dw, dh,
                                 _p(dst, C.c_uint8))
     return dst
+
+
+def steger_improved(img: np.ndarray, sigma: float = 3.0, threshold: int = 200, response_threshold: float = 0.5,
+                    per_row: bool = False) -> np.ndarray:
+    """ImprovedStegerExtractor.extract_centerline (per_row=False) / extract_centerline_optimized (per_row=True)
+    (improved_steger.py:39-223) -> (N,2) float64 (x, y)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 3 if img.ndim == 3 else 1
+    h, w = img.shape[:2]
+    xy = np.empty((w * h, 2), np.float64)
+    n = C.c_int(0)
+    rc = lib().orc_steger_improved(_p(img, C.c_uint8), ch, w, h, C.c_double(sigma), int(threshold), C.c_double(response_threshold),
+                                   int(per_row), _p(xy, C.c_double), w * h, C.byref(n))
+    assert rc == 0
+    return xy[: n.value].copy()
+
+
+def hybrid_extract(bgr: np.ndarray, hsv_lower=(50, 100, 180), hsv_upper=(70, 255, 255), threshold: int = 200, sigma: float = 2.0,
+                   want_mask: bool = False):
+    """HybridLaserExtractor.extract_centerline (improved_steger.py:250-344) -> (N,2) float64 (x, y)."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    xy = np.empty((h, 2), np.float64)
+    n = C.c_int(0)
+    lo = (C.c_int * 3)(*[int(v) for v in hsv_lower])
+    hi = (C.c_int * 3)(*[int(v) for v in hsv_upper])
+    mask = np.empty((h, w), np.uint8) if want_mask else None
+    rc = lib().orc_hybrid_extract(_p(bgr, C.c_uint8), w, h, lo, hi, int(threshold), C.c_double(sigma), _p(xy, C.c_double), h, C.byref(n),
+                                  _p(mask, C.c_uint8) if want_mask else None)
+    assert rc == 0
+    pts = xy[: n.value].copy()
+    return (pts, mask) if want_mask else pts

@@ -563,3 +563,70 @@ def test_camera_manager_rectifies_like_the_reference_flow(gpu, O, tmp_path):
     d16 = O.sgbm_compute(p, O.bgr2gray(wl), O.bgr2gray(wr))
     want = O.depth_from_disp16(d16, Q)
     assert np.array_equal(depth, want) and (depth > 0).mean() > 0.2
+
+
+def _match_points(got, want, tol):
+    """Same point sets up to `tol` px; a pixel that sits exactly on an acceptance threshold may be decided
+    differently by one rounding, so up to 0.5 % unmatched points are tolerated and counted."""
+    got, want = np.asarray(got, np.float64).reshape(-1, 2), np.asarray(want, np.float64).reshape(-1, 2)
+    if len(got) == len(want) and (len(want) == 0 or np.abs(got - want).max() <= tol):
+        return 0
+    from scipy.spatial import cKDTree
+    d1 = cKDTree(want).query(got)[0] if len(want) else np.full(len(got), np.inf)
+    d2 = cKDTree(got).query(want)[0] if len(got) else np.full(len(want), np.inf)
+    return int((d1 > tol).sum() + (d2 > tol).sum())
+
+
+def test_improved_steger_variants_match_oracle(gpu, O):
+    """ImprovedStegerExtractor (both methods) and HybridLaserExtractor against the oracle: identical point lists
+    (count and order) with coordinates within 1e-3 px (the GPU returns float32 coordinates)."""
+    from laser_3d_reconstruction_amd.improved_steger import ImprovedStegerExtractor, HybridLaserExtractor
+
+    S = _S()
+    rng = np.random.default_rng(4)
+    imgs = [_pair(640, 360, 64, 0)[0], _pair(333, 131, 32, 2)[0]]
+    noisy = imgs[0].copy()
+    noisy[rng.random(noisy.shape[:2]) < 0.01] = (150, 255, 150)          # isolated bright green pixels
+    imgs.append(noisy)
+    imgs.append(rng.integers(190, 256, (90, 130)).astype(np.uint8))      # dense gray input, every pixel a candidate
+    total = 0
+    for sigma, thr, resp in [(3.0, 200, 0.5), (1.5, 180, 0.3), (2.0, 210, 1.0)]:
+        ex = ImprovedStegerExtractor(sigma, thr, resp)
+        for im in imgs:
+            for per_row in (False, True):
+                want = O.steger_improved(im, sigma, thr, resp, per_row)
+                got = ex.extract_points(im, per_row)
+                assert len(got) == len(want), (im.shape, sigma, per_row)
+                if len(want):
+                    assert np.abs(got - want).max() <= 1e-3
+                total += len(want)
+    assert total > 5000
+    pts = ImprovedStegerExtractor().extract_centerline_optimized(imgs[0])
+    assert isinstance(pts, list) and isinstance(pts[0], tuple) and isinstance(pts[0][0], float)
+    ys = [p[1] for p in pts]
+    assert ys == sorted(ys) and len(set(ys)) == len(ys) and all(float(y).is_integer() for y in ys)
+    # a clean Gaussian ridge: the per-row centre follows the analytic one to within half a pixel only -- the
+    # reference divides a Sobel gradient (gain 8) by a Sobel-of-Sobel curvature (gain 64), so its sub-pixel
+    # offsets come out 8 times too small and the result stays close to the pixel grid
+    x = np.arange(200)[None, :]
+    y = np.arange(120)[:, None]
+    c = 80.3 + 0.25 * y
+    ridge = np.clip(30 + 220 * np.exp(-0.5 * ((x - c) / 2.5) ** 2), 0, 255).astype(np.uint8)
+    got = ImprovedStegerExtractor(2.0, 150, 0.5).extract_points(ridge, per_row=True)
+    assert len(got) == 118 and np.abs(got[:, 0] - c[got[:, 1].astype(int), 0]).max() < 0.6
+    # hybrid: the reference's default colour range and a wider one
+    hyb_total = 0
+    for lo, hi, thr, sigma in [((50, 100, 180), (70, 255, 255), 200, 2.0), ((40, 50, 100), (80, 255, 255), 200, 2.0), ((35, 40, 90), (85, 255, 255), 150, 3.0)]:
+        hy = HybridLaserExtractor(np.array(lo), np.array(hi), thr, sigma)
+        for im in imgs[:3]:
+            want, wmask = O.hybrid_extract(im, lo, hi, thr, sigma, want_mask=True)
+            got, gmask = hy.extract_points(im, want_mask=True)
+            assert np.array_equal(gmask, wmask)
+            assert len(got) == len(want)
+            if len(want):
+                assert np.abs(got - want).max() <= 1e-3
+            hyb_total += len(want)
+    assert hyb_total > 300
+    assert ImprovedStegerExtractor().extract_centerline(np.zeros((40, 60, 3), np.uint8)) == []
+    assert HybridLaserExtractor().extract_centerline(np.zeros((40, 60, 3), np.uint8)) == []
+    assert ImprovedStegerExtractor().extract_centerline(np.full((2, 60), 255, np.uint8)) == []      # no interior rows
