@@ -285,6 +285,26 @@ int l3d_reconstruct_from_depth(const double *uv, int n, const float *depth, int 
 int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv9, const double *plane4,
                           int refraction, double n_water, double *xyz, int device);
 
+/* replaces ImprovedLaserReconstructor.reconstruct_from_disparity (window_size = 0,
+ * improved_reconstruction.py:37-86) and .reconstruct_with_interpolation (window_size odd >= 1:
+ * median of the valid disparities of the window, :88-152).  uv: n (x, y) doubles; disparity
+ * [height][width] float32 (or float64 with disparity_is_f64); Q16: the 4x4 reprojection matrix,
+ * of which fx = Q[2][3], baseline = 1/Q[3][2], cx = -Q[0][3], cy = -Q[1][3] are used (:26-30);
+ * xyz: float32 triples of the kept points (first *n_out rows, input order kept). */
+int l3d_triangulate_disparity(const double *uv, int n, const void *disparity, int disparity_is_f64, int width,
+                              int height, const double *Q16, int window_size, double min_disparity, float *xyz,
+                              int *n_out, int device);
+/* same on device-resident operands (float32 map), no compaction: d_xyz [n][3], d_keep [n] (1 where
+ * the reference appends the point) */
+int l3d_triangulate_disparity_device(const double *d_uv, int n, const float *d_disparity, int width, int height,
+                                     const double *Q16, int window_size, double min_disparity, float *d_xyz,
+                                     int *d_keep, void *stream);
+/* replaces ImprovedLaserReconstructor.create_laser_depth_map (improved_reconstruction.py:154-186)
+ * with image_shape = the disparity map's shape: depth [height][width] float32, zero except at the
+ * rounded laser pixels. */
+int l3d_laser_depth_map(const double *uv, int n, const void *disparity, int disparity_is_f64, int width, int height,
+                        const double *Q16, float *depth, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,103 @@ __global__ void __launch_bounds__(256) k_from_depth(const double *__restrict__ u
     keep[i] = k;
 }
 
+// ImprovedLaserReconstructor (improved_reconstruction.py:17-186): triangulation straight from the disparity map.
+struct TriArgs {
+    double fx, baseline, cx, cy;
+    double min_disparity;
+    int W, H, window; // window 0 = nearest pixel, else odd window edge for the median
+};
+
+// Python's int(round(v)): round half to even; false for NaN / out of int range
+__device__ __forceinline__ bool py_round_int(double v, int &out)
+{
+    if (!(v == v) || !(fabs(v) < 2147483000.0)) return false;
+    out = (int)rint(v);
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ bool disp_valid(T v, double min_disparity)
+{
+    const double d = (double)v;
+    return d >= min_disparity && !isnan(d) && !isinf(d);
+}
+
+// value of rank r (0-based, ascending) among the valid disparities of the window: counted, not sorted, so no
+// per-thread array is needed (windows are at most a few dozen pixels and only laser pixels are processed)
+template <typename T>
+__device__ T window_rank(const T *__restrict__ disp, const TriArgs &a, int px, int py, int hw, int r)
+{
+    for (int y = py - hw; y <= py + hw; y++)
+        for (int x = px - hw; x <= px + hw; x++) {
+            const T v = disp[(size_t)y * a.W + x];
+            if (!disp_valid(v, a.min_disparity)) continue;
+            int less = 0, equal = 0;
+            for (int yy = py - hw; yy <= py + hw; yy++)
+                for (int xx = px - hw; xx <= px + hw; xx++) {
+                    const T u = disp[(size_t)yy * a.W + xx];
+                    if (!disp_valid(u, a.min_disparity)) continue;
+                    less += u < v;
+                    equal += u == v;
+                }
+            if (less <= r && r < less + equal) return v;
+        }
+    return (T)0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_triangulate(const double *__restrict__ uv, int n, const T *__restrict__ disp, TriArgs a,
+                                                     float *__restrict__ xyz, int *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = 0;
+    int px, py;
+    if (!py_round_int(uv[2 * i], px) || !py_round_int(uv[2 * i + 1], py)) return;
+    double d;
+    if (a.window == 0) {
+        if (px < 0 || px >= a.W || py < 0 || py >= a.H) return;
+        const T v = disp[(size_t)py * a.W + px];
+        if (!disp_valid(v, a.min_disparity)) return;
+        d = (double)v;
+    } else {
+        const int hw = a.window / 2;
+        if (px < hw || px >= a.W - hw || py < hw || py >= a.H - hw) return;
+        int k = 0;
+        for (int y = py - hw; y <= py + hw; y++)
+            for (int x = px - hw; x <= px + hw; x++) k += disp_valid(disp[(size_t)y * a.W + x], a.min_disparity);
+        if (k == 0) return;
+        if (k & 1) d = (double)window_rank(disp, a, px, py, hw, k / 2);
+        else {
+            // np.median averages the two middle values in the map's own type
+            const T lo = window_rank(disp, a, px, py, hw, k / 2 - 1), hi = window_rank(disp, a, px, py, hw, k / 2);
+            d = (double)((T)(lo + hi) / (T)2);
+        }
+    }
+    const double Z = (a.fx * a.baseline) / d;
+    const double X = (px - a.cx) * Z / a.fx, Y = (py - a.cy) * Z / a.fx; // Y / fx as well: the reference's formula
+    if (Z > 0 && Z < 10.0) {
+        xyz[3 * i] = (float)X; xyz[3 * i + 1] = (float)Y; xyz[3 * i + 2] = (float)Z;
+        keep[i] = 1;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_laser_depth(const double *__restrict__ uv, int n, const T *__restrict__ disp, TriArgs a,
+                                                     float *__restrict__ depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px, py;
+    if (!py_round_int(uv[2 * i], px) || !py_round_int(uv[2 * i + 1], py)) return;
+    if (px < 0 || px >= a.W || py < 0 || py >= a.H) return;
+    const double d = (double)disp[(size_t)py * a.W + px];
+    if (d > 1.0 && !isnan(d)) {
+        const double z = (a.fx * a.baseline) / d;
+        if (0 < z && z < 10.0) depth[(size_t)py * a.W + px] = (float)z; // several points on one pixel write the same value
+    }
+}
+
 struct PlaneArgs {
     double kinv[9];
     double plane[4];
@@ -302,5 +399,95 @@ extern "C" int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv
     hipLaunchKernelGGL(k_plane, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, a, (double *)dxyz.p);
     L3D_HIP_CHECK(hipGetLastError());
     L3D_HIP_CHECK(hipMemcpy(xyz, dxyz.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
+
+static TriArgs tri_args(const double *Q, int W, int H, int window, double min_disparity)
+{
+    TriArgs a;
+    a.fx = Q[2 * 4 + 3]; a.baseline = 1.0 / Q[3 * 4 + 2]; a.cx = -Q[0 * 4 + 3]; a.cy = -Q[1 * 4 + 3];
+    a.min_disparity = min_disparity; a.W = W; a.H = H; a.window = window;
+    return a;
+}
+
+extern "C" int l3d_triangulate_disparity(const double *uv, int n, const void *disparity, int disparity_is_f64, int width, int height,
+                                         const double *Q16, int window_size, double min_disparity, float *xyz, int *n_out, int device)
+{
+    L3D_REQUIRE(n_out, "l3d_triangulate_disparity: null argument");
+    *n_out = 0;
+    L3D_REQUIRE(n >= 0 && width > 0 && height > 0, "l3d_triangulate_disparity: bad size");
+    L3D_REQUIRE(window_size == 0 || (window_size >= 1 && window_size <= 31), "l3d_triangulate_disparity: window_size %d outside [1, 31] (0 = nearest pixel)", window_size);
+    if (n == 0) return L3D_OK;
+    L3D_REQUIRE(uv && disparity && Q16 && xyz, "l3d_triangulate_disparity: null argument");
+    int rc = check_device(device, "l3d_triangulate_disparity");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    const size_t esz = disparity_is_f64 ? 8 : 4;
+    DevBuf duv, ddisp, dxyz, dkeep;
+    L3D_HIP_CHECK(duv.alloc((size_t)n * 16));
+    L3D_HIP_CHECK(ddisp.alloc((size_t)width * height * esz));
+    L3D_HIP_CHECK(dxyz.alloc((size_t)n * 12));
+    L3D_HIP_CHECK(dkeep.alloc((size_t)n * 4));
+    L3D_HIP_CHECK(hipMemcpy(duv.p, uv, (size_t)n * 16, hipMemcpyHostToDevice));
+    L3D_HIP_CHECK(hipMemcpy(ddisp.p, disparity, (size_t)width * height * esz, hipMemcpyHostToDevice));
+    const TriArgs a = tri_args(Q16, width, height, window_size, min_disparity);
+    if (disparity_is_f64)
+        hipLaunchKernelGGL(k_triangulate<double>, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, (const double *)ddisp.p, a,
+                           (float *)dxyz.p, (int *)dkeep.p);
+    else
+        hipLaunchKernelGGL(k_triangulate<float>, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, (const float *)ddisp.p, a,
+                           (float *)dxyz.p, (int *)dkeep.p);
+    L3D_HIP_CHECK(hipGetLastError());
+    std::vector<float> tmp((size_t)n * 3);
+    std::vector<int> keep(n);
+    L3D_HIP_CHECK(hipMemcpy(tmp.data(), dxyz.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    L3D_HIP_CHECK(hipMemcpy(keep.data(), dkeep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int m = 0;
+    for (int i = 0; i < n; i++)
+        if (keep[i]) {
+            xyz[3 * m] = tmp[3 * i]; xyz[3 * m + 1] = tmp[3 * i + 1]; xyz[3 * m + 2] = tmp[3 * i + 2];
+            m++;
+        }
+    *n_out = m;
+    return L3D_OK;
+}
+
+extern "C" int l3d_triangulate_disparity_device(const double *d_uv, int n, const float *d_disparity, int width, int height, const double *Q16,
+                                                int window_size, double min_disparity, float *d_xyz, int *d_keep, void *stream)
+{
+    L3D_REQUIRE(n >= 0 && width > 0 && height > 0, "l3d_triangulate_disparity_device: bad size");
+    L3D_REQUIRE(window_size == 0 || (window_size >= 1 && window_size <= 31), "l3d_triangulate_disparity_device: window_size %d outside [1, 31]", window_size);
+    if (n == 0) return L3D_OK;
+    L3D_REQUIRE(d_uv && d_disparity && Q16 && d_xyz && d_keep, "l3d_triangulate_disparity_device: null argument");
+    const TriArgs a = tri_args(Q16, width, height, window_size, min_disparity);
+    hipLaunchKernelGGL(k_triangulate<float>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d_uv, n, d_disparity, a, d_xyz, d_keep);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_laser_depth_map(const double *uv, int n, const void *disparity, int disparity_is_f64, int width, int height,
+                                   const double *Q16, float *depth, int device)
+{
+    L3D_REQUIRE(n >= 0 && width > 0 && height > 0 && depth && Q16 && (n == 0 || (uv && disparity)), "l3d_laser_depth_map: bad argument");
+    int rc = check_device(device, "l3d_laser_depth_map");
+    if (rc) return rc;
+    DeviceGuard dg(device);
+    const size_t esz = disparity_is_f64 ? 8 : 4, px = (size_t)width * height;
+    DevBuf duv, ddisp, ddep;
+    L3D_HIP_CHECK(ddep.alloc(px * 4));
+    L3D_HIP_CHECK(hipMemset(ddep.p, 0, px * 4));
+    if (n > 0) {
+        L3D_HIP_CHECK(duv.alloc((size_t)n * 16));
+        L3D_HIP_CHECK(ddisp.alloc(px * esz));
+        L3D_HIP_CHECK(hipMemcpy(duv.p, uv, (size_t)n * 16, hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(ddisp.p, disparity, px * esz, hipMemcpyHostToDevice));
+        const TriArgs a = tri_args(Q16, width, height, 0, 1.0);
+        if (disparity_is_f64)
+            hipLaunchKernelGGL(k_laser_depth<double>, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, (const double *)ddisp.p, a, (float *)ddep.p);
+        else
+            hipLaunchKernelGGL(k_laser_depth<float>, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, (const float *)ddisp.p, a, (float *)ddep.p);
+        L3D_HIP_CHECK(hipGetLastError());
+    }
+    L3D_HIP_CHECK(hipMemcpy(depth, ddep.p, px * 4, hipMemcpyDeviceToHost));
     return L3D_OK;
 }

@@ -1374,3 +1374,81 @@ ORC_API int orc_hybrid_extract(const uint8_t *bgr, int W, int H, const int *lowe
     free(m0); free(m1); free(gf);
     return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Disparity-domain triangulation (improved_reconstruction.py:37-186).       */
+/* PINNED: golden vectors generated from the reference itself                 */
+/* (tests/golden/reconstruction_golden.json, disparity_cases*).              */
+/* ------------------------------------------------------------------------ */
+static double disp_at(const void *disp, int is_f64, size_t i) { return is_f64 ? ((const double *)disp)[i] : (double)((const float *)disp)[i]; }
+
+/* Python int(round(v)) for a finite double in int range: round half to even */
+static int py_round_int(double v, int *ok)
+{
+    *ok = (v == v) && fabs(v) < 2147483000.0;
+    return *ok ? (int)nearbyint(v) : 0;
+}
+
+static int cmp_double(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
+
+/* window_size == 0: reconstruct_from_disparity (nearest pixel); otherwise reconstruct_with_interpolation (median of the valid
+ * disparities of a window_size x window_size window).  xyz: float32 triples of the kept points, input order. */
+ORC_API int orc_triangulate_disparity(const double *uv, int n, const void *disp, int is_f64, int W, int H, const double *Q,
+                                      int window_size, double min_disparity, float *xyz, int *n_out)
+{
+    const double fx = Q[2 * 4 + 3], baseline = 1.0 / Q[3 * 4 + 2], cx = -Q[0 * 4 + 3], cy = -Q[1 * 4 + 3];
+    const int hw = window_size / 2;
+    double *win = (double *)malloc(sizeof(double) * (size_t)(window_size > 0 ? window_size * window_size : 1));
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        int okx, oky;
+        const int px = py_round_int(uv[2 * i], &okx), py = py_round_int(uv[2 * i + 1], &oky);
+        if (!okx || !oky) continue;
+        double d;
+        if (window_size == 0) {
+            if (px < 0 || px >= W || py < 0 || py >= H) continue;
+            d = disp_at(disp, is_f64, (size_t)py * W + px);
+            if (d < min_disparity || isnan(d) || isinf(d)) continue;
+        } else {
+            if (px < hw || px >= W - hw || py < hw || py >= H - hw) continue;
+            int k = 0;
+            for (int y = py - hw; y <= py + hw; y++)
+                for (int x = px - hw; x <= px + hw; x++) {
+                    const double v = disp_at(disp, is_f64, (size_t)y * W + x);
+                    if (v >= min_disparity && !isnan(v) && !isinf(v)) win[k++] = v;
+                }
+            if (k == 0) continue;
+            qsort(win, (size_t)k, sizeof(double), cmp_double);
+            if (k & 1) d = win[k / 2];
+            else if (is_f64) d = (win[k / 2 - 1] + win[k / 2]) / 2.0;
+            else d = (double)(((float)win[k / 2 - 1] + (float)win[k / 2]) / 2.0f);   /* np.median of float32 averages in float32 */
+        }
+        const double Z = (fx * baseline) / d;
+        const double X = (px - cx) * Z / fx, Y = (py - cy) * Z / fx;   /* Y is divided by fx as well: the reference's formula */
+        if (Z > 0 && Z < 10.0) {
+            xyz[3 * m] = (float)X; xyz[3 * m + 1] = (float)Y; xyz[3 * m + 2] = (float)Z;
+            m++;
+        }
+    }
+    free(win);
+    *n_out = m;
+    return 0;
+}
+
+/* create_laser_depth_map: depth (float32, [H][W], zero elsewhere) at the rounded laser pixels */
+ORC_API int orc_laser_depth_map(const double *uv, int n, const void *disp, int is_f64, int W, int H, const double *Q, float *depth)
+{
+    const double fx = Q[2 * 4 + 3], baseline = 1.0 / Q[3 * 4 + 2];
+    memset(depth, 0, sizeof(float) * (size_t)W * H);
+    for (int i = 0; i < n; i++) {
+        int okx, oky;
+        const int px = py_round_int(uv[2 * i], &okx), py = py_round_int(uv[2 * i + 1], &oky);
+        if (!okx || !oky || px < 0 || px >= W || py < 0 || py >= H) continue;
+        const double d = disp_at(disp, is_f64, (size_t)py * W + px);
+        if (d > 1.0 && !isnan(d)) {
+            const double z = (fx * baseline) / d;
+            if (0 < z && z < 10.0) depth[(size_t)py * W + px] = (float)z;
+        }
+    }
+    return 0;
+}

@@ -367,3 +367,30 @@ def hybrid_extract(bgr: np.ndarray, hsv_lower=(50, 100, 180), hsv_upper=(70, 255
     assert rc == 0
     pts = xy[: n.value].copy()
     return (pts, mask) if want_mask else pts
+
+
+def triangulate_disparity(uv, disp: np.ndarray, Q, window_size: int = 0, min_disparity: float = 1.0) -> np.ndarray:
+    """ImprovedLaserReconstructor.reconstruct_from_disparity (window_size=0) / reconstruct_with_interpolation
+    (improved_reconstruction.py:37-152) -> (M,3) float32."""
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    is64 = disp.dtype == np.float64
+    disp = np.ascontiguousarray(disp, np.float64 if is64 else np.float32)
+    h, w = disp.shape
+    q = np.ascontiguousarray(Q, np.float64)
+    xyz = np.empty((max(len(uv), 1), 3), np.float32)
+    n = C.c_int(0)
+    lib().orc_triangulate_disparity(_p(uv, C.c_double), len(uv), disp.ctypes.data_as(C.c_void_p), int(is64), w, h, _p(q, C.c_double),
+                                    int(window_size), C.c_double(min_disparity), _p(xyz, C.c_float), C.byref(n))
+    return xyz[: n.value].copy()
+
+
+def laser_depth_map(uv, disp: np.ndarray, Q) -> np.ndarray:
+    """ImprovedLaserReconstructor.create_laser_depth_map (improved_reconstruction.py:154-186) with image_shape = disp.shape."""
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    is64 = disp.dtype == np.float64
+    disp = np.ascontiguousarray(disp, np.float64 if is64 else np.float32)
+    h, w = disp.shape
+    q = np.ascontiguousarray(Q, np.float64)
+    out = np.empty((h, w), np.float32)
+    lib().orc_laser_depth_map(_p(uv, C.c_double), len(uv), disp.ctypes.data_as(C.c_void_p), int(is64), w, h, _p(q, C.c_double), _p(out, C.c_float))
+    return out

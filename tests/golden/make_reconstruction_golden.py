@@ -97,6 +97,37 @@ def main():
             "median3": np.asarray(b, np.float64).reshape(-1, 3).tolist(),
             "laser_depth": np.asarray(c, np.float64).tolist(),
         })
+    # more of the same with other windows / thresholds / map dtypes, and half-integer pixel coordinates
+    # (Python's round() goes to the even neighbour) on a map with many exact ties for the median
+    cases["disparity_cases_ext"] = []
+    for k, (win, mind, dt) in enumerate([(3, 1.0, np.float32), (5, 1.0, np.float32), (5, 0.5, np.float64), (1, 2.0, np.float32),
+                                         (7, 1.0, np.float32)]):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ir = imp.ImprovedLaserReconstructor(Qp)
+        h, w = 24, 32
+        disp = np.round(rng.uniform(-2.0, 30.0, size=(h, w)) * (4 if k % 2 else 16)) / (4 if k % 2 else 16)
+        disp[rng.uniform(size=(h, w)) < 0.3] = -1.0
+        disp[2, 3] = np.nan
+        disp[7, 9] = np.inf
+        disp[8, 9] = -np.inf
+        disp[10, 10] = 0.05          # a depth beyond 10 m
+        disp = disp.astype(dt)
+        pts = rng.uniform([-1, -1], [w + 1, h + 1], size=(80, 2))
+        grid = np.array([[x + 0.5, y + 0.5] for x in range(0, w, 3) for y in range(0, h, 5)])
+        pts = np.concatenate([pts, grid, [[3.0, 2.0], [9.0, 7.0], [9.0, 8.0], [10.0, 10.0], [-0.5, 0.5], [w - 0.5, h - 0.5]]])
+        lp = [(float(a), float(b)) for a, b in pts]
+        with np.errstate(all="ignore"):
+            a = ir.reconstruct_from_disparity(lp, disp, min_disparity=mind)
+            b = ir.reconstruct_with_interpolation(lp, disp, window_size=win, min_disparity=mind)
+            c = ir.create_laser_depth_map(lp, disp, (h, w))
+        enc = lambda v: None if np.isnan(v) else ("inf" if v == np.inf else ("-inf" if v == -np.inf else float(v)))
+        cases["disparity_cases_ext"].append({
+            "Q": Qp.tolist(), "dtype": np.dtype(dt).name, "window_size": win, "min_disparity": mind,
+            "disparity": [[enc(v) for v in row] for row in disp], "uv": pts.tolist(),
+            "nearest": np.asarray(a, np.float64).reshape(-1, 3).tolist(),
+            "median": np.asarray(b, np.float64).reshape(-1, 3).tolist(),
+            "laser_depth": np.asarray(c, np.float64).tolist(),
+        })
     with open(OUT, "w") as f:
         json.dump(cases, f)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

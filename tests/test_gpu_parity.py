@@ -630,3 +630,50 @@ def test_improved_steger_variants_match_oracle(gpu, O):
     assert ImprovedStegerExtractor().extract_centerline(np.zeros((40, 60, 3), np.uint8)) == []
     assert HybridLaserExtractor().extract_centerline(np.zeros((40, 60, 3), np.uint8)) == []
     assert ImprovedStegerExtractor().extract_centerline(np.full((2, 60), 255, np.uint8)) == []      # no interior rows
+
+
+def test_disparity_triangulation_matches_reference_golden_and_oracle(gpu, O, golden):
+    """ImprovedLaserReconstructor on the GPU: bit-identical to the reference's own outputs (golden vectors) and to
+    the oracle on a full-size disparity map with the laser points of the Steger extractor."""
+    from laser_3d_reconstruction_amd.improved_reconstruction import ImprovedLaserReconstructor, fix_roi_alignment
+
+    def dec(rows, dt):
+        return np.array([[np.nan if v is None else (np.inf if v == "inf" else (-np.inf if v == "-inf" else v)) for v in r] for r in rows], dt)
+
+    for c in golden["disparity_cases"]:
+        d = dec(c["disparity"], np.float32)
+        d[tuple(c["inf_at"])] = np.inf
+        r = ImprovedLaserReconstructor(np.array(c["Q"]))
+        lp = [tuple(p) for p in c["uv"]]
+        assert np.array_equal(np.asarray(r.reconstruct_from_disparity(lp, d), np.float64).reshape(-1, 3), np.array(c["nearest"]).reshape(-1, 3))
+        assert np.array_equal(np.asarray(r.reconstruct_with_interpolation(lp, d), np.float64).reshape(-1, 3), np.array(c["median3"]).reshape(-1, 3))
+        assert np.array_equal(r.create_laser_depth_map(lp, d, d.shape).astype(np.float64), np.array(c["laser_depth"]))
+    for c in golden["disparity_cases_ext"]:
+        d = dec(c["disparity"], np.dtype(c["dtype"]))
+        r = ImprovedLaserReconstructor(np.array(c["Q"]))
+        lp = [tuple(p) for p in c["uv"]]
+        a = r.reconstruct_from_disparity(lp, d, min_disparity=c["min_disparity"])
+        b = r.reconstruct_with_interpolation(lp, d, window_size=c["window_size"], min_disparity=c["min_disparity"])
+        assert a.dtype == np.float32 and np.array_equal(a.astype(np.float64), np.array(c["nearest"]))
+        assert np.array_equal(b.astype(np.float64), np.array(c["median"]))
+        assert np.array_equal(r.create_laser_depth_map(lp, d, d.shape).astype(np.float64), np.array(c["laser_depth"]))
+    # the reference's empty results
+    r = ImprovedLaserReconstructor(np.array(golden["disparity_cases"][1]["Q"]))
+    assert r.reconstruct_from_disparity([], np.zeros((4, 4), np.float32)).shape == (0,)
+    assert r.reconstruct_with_interpolation([(1.0, 1.0)], np.full((4, 4), -1.0, np.float32)).shape == (0,)
+    # full size: SGBM disparity of a synthetic pair, laser points from the extractor
+    from laser_3d_reconstruction_amd import FastStegerExtractor
+    W, H = 640, 360
+    lb, rb = _pair(W, H, 64, 1)
+    d16 = _sgbm(**_ref_ctor(64, 5)).compute(O.bgr2gray(lb), O.bgr2gray(rb))
+    disp = d16.astype(np.float32) / 16.0
+    pts = FastStegerExtractor().extract_centerline(lb)
+    Q = np.array([[1, 0, 0, -W / 2], [0, 1, 0, -H / 2], [0, 0, 0, 420.0], [0, 0, 1 / 0.06, 0]])
+    r = ImprovedLaserReconstructor(Q)
+    for win in (0, 3, 5, 9):
+        got = r.reconstruct_from_disparity(pts, disp) if win == 0 else r.reconstruct_with_interpolation(pts, disp, window_size=win)
+        want = O.triangulate_disparity(pts, disp, Q, win)
+        assert len(want) > 300 and np.array_equal(got, want)
+    assert np.array_equal(r.create_laser_depth_map(pts, disp, (H, W)), O.laser_depth_map(pts, disp, Q))
+    l2, r2 = fix_roi_alignment(lb, rb, (3, 2, 600, 350), (10, 0, 620, 340))
+    assert l2.shape == (338, 593, 3) and np.array_equal(r2, rb[2:340, 10:603])

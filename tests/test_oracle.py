@@ -293,3 +293,28 @@ def test_init_undistort_rectify_map_properties(O):
     xd = x * kr + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
     yd = y * kr + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
     assert np.abs(mx - (xd * 300 + 160)).max() < 1e-3 and np.abs(my - (yd * 305 + 120)).max() < 1e-3
+
+
+def _dec_disp(rows, dt):
+    return np.array([[np.nan if v is None else (np.inf if v == "inf" else (-np.inf if v == "-inf" else v)) for v in r] for r in rows], dt)
+
+
+def test_disparity_triangulation_matches_reference_golden(O, golden):
+    """The oracle against ImprovedLaserReconstructor itself (vectors generated by importing the reference,
+    tests/golden/make_reconstruction_golden.py): bit for bit."""
+    n = 0
+    for c in golden["disparity_cases"]:
+        d = _dec_disp(c["disparity"], np.float32)
+        d[tuple(c["inf_at"])] = np.inf
+        assert np.array_equal(O.triangulate_disparity(c["uv"], d, c["Q"], 0).astype(np.float64).reshape(-1, 3), np.array(c["nearest"]).reshape(-1, 3))
+        assert np.array_equal(O.triangulate_disparity(c["uv"], d, c["Q"], 3).astype(np.float64).reshape(-1, 3), np.array(c["median3"]).reshape(-1, 3))
+        assert np.array_equal(O.laser_depth_map(c["uv"], d, c["Q"]).astype(np.float64), np.array(c["laser_depth"]))
+    for c in golden["disparity_cases_ext"]:
+        d = _dec_disp(c["disparity"], np.dtype(c["dtype"]))
+        a = O.triangulate_disparity(c["uv"], d, c["Q"], 0, c["min_disparity"])
+        b = O.triangulate_disparity(c["uv"], d, c["Q"], c["window_size"], c["min_disparity"])
+        assert np.array_equal(a.astype(np.float64).reshape(-1, 3), np.array(c["nearest"]).reshape(-1, 3))
+        assert np.array_equal(b.astype(np.float64).reshape(-1, 3), np.array(c["median"]).reshape(-1, 3))
+        assert np.array_equal(O.laser_depth_map(c["uv"], d, c["Q"]).astype(np.float64), np.array(c["laser_depth"]))
+        n += len(a) + len(b)
+    assert n > 500
