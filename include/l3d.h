@@ -305,6 +305,25 @@ int l3d_triangulate_disparity_device(const double *d_uv, int n, const float *d_d
 int l3d_laser_depth_map(const double *uv, int n, const void *disparity, int disparity_is_f64, int width, int height,
                         const double *Q16, float *depth, int device);
 
+/* ---------------------------------------------------------------------------
+ * Point-cloud post-processing (PointCloudProcessor without Open3D, utils/point_cloud.py).
+ * Host pointers; points are n x 3 doubles.
+ * ------------------------------------------------------------------------- */
+/* replaces PointCloudProcessor._simple_voxel_downsample behind voxel_downsample
+ * (utils/point_cloud.py:31-79): one point per occupied voxel floor(p / voxel_size), the
+ * mean of the voxel's points, in order of each voxel's first point.  out: room for n points. */
+int l3d_voxel_downsample(const double *points, int n, double voxel_size, double *out, int *n_out, int device);
+/* replaces PointCloudProcessor._simple_outlier_removal behind statistical_outlier_removal
+ * (utils/point_cloud.py:81-132): a point is kept when mean < mean + std_ratio * std of its
+ * nb_neighbors nearest-neighbour distances (true unless the deviation vanishes or the
+ * cloud has fewer than nb_neighbors + 1 points); clouds smaller than nb_neighbors are
+ * returned unchanged.  out: room for n points. */
+int l3d_sor_simple(const double *points, int n, int nb_neighbors, double std_ratio, double *out, int *n_out,
+                   int device);
+/* nearest-neighbour distance of every point: the cKDTree.query(points, k=2)[:, 1] of
+ * compute_point_cloud_metrics (utils/point_cloud.py:270-276). */
+int l3d_nn_distances(const double *points, int n, double *nn, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,10 @@
 """MI355X-native stereo-depth + laser centre-line hot path.
 
-Exports the same five names as the reference package (__init__.py:11-24);
-PointCloudProcessor (post-hoc point-cloud IO) is outside the accelerated path
-and is not provided.
+Exports the same names as the reference package (__init__.py:11-24).  The
+modules the reference keeps at its top level are mirrored as submodules:
+``improved_steger`` (ImprovedStegerExtractor, HybridLaserExtractor),
+``improved_reconstruction`` (ImprovedLaserReconstructor, fix_roi_alignment),
+``camera.rectify`` (stereo_rectify, Rectifier).
 """
 __version__ = "0.1.0"
 
@@ -10,6 +12,7 @@ from .config import Config
 from .core.laser_extractor import FastStegerExtractor, SimpleLaserExtractor
 from .core.reconstruction import Reconstructor
 from .camera.single_usb_stereo_camera import SingleUSBStereoCameraManager
+from .utils.point_cloud import PointCloudProcessor
 
 # the reference's north-star text calls the extractor "StegerExtractor"
 StegerExtractor = FastStegerExtractor
@@ -20,5 +23,6 @@ __all__ = [
     'StegerExtractor',
     'Reconstructor',
     'SingleUSBStereoCameraManager',
+    'PointCloudProcessor',
     'Config',
 ]

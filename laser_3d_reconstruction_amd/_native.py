@@ -124,6 +124,9 @@ def _load():
         "l3d_triangulate_disparity": (i, [vp, i, vp, i, i, i, vp, i, C.c_double, vp, pi, i]),
         "l3d_triangulate_disparity_device": (i, [vp, i, vp, i, i, vp, i, C.c_double, vp, vp, vp]),
         "l3d_laser_depth_map": (i, [vp, i, vp, i, i, i, vp, vp, i]),
+        "l3d_voxel_downsample": (i, [vp, i, C.c_double, vp, pi, i]),
+        "l3d_sor_simple": (i, [vp, i, i, C.c_double, vp, pi, i]),
+        "l3d_nn_distances": (i, [vp, i, vp, i]),
         "l3d_reconstruct_plane": (i, [vp, i, vp, vp, i, C.c_double, vp, i]),
     }
     for name, (res, args) in sig.items():

@@ -1452,3 +1452,124 @@ ORC_API int orc_laser_depth_map(const double *uv, int n, const void *disp, int i
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Point-cloud post-processing: PointCloudProcessor without Open3D            */
+/* (utils/point_cloud.py:55-79, 108-132, 239-278).  PINNED: golden vectors    */
+/* generated from the reference itself (tests/golden/pointcloud_golden.npz).  */
+/* ------------------------------------------------------------------------ */
+
+/* numpy's pairwise summation of a contiguous double array (np.add.reduce, hence np.mean / np.std of 1-D data) */
+static double np_pairwise_sum(const double *a, size_t n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (size_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+typedef struct { long long k[3]; int idx; } vox_rec;
+static int cmp_vox(const void *a, const void *b)
+{
+    const vox_rec *x = (const vox_rec *)a, *y = (const vox_rec *)b;
+    for (int c = 0; c < 3; c++)
+        if (x->k[c] != y->k[c]) return x->k[c] < y->k[c] ? -1 : 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+typedef struct { int head, start, count; } vox_seg;
+static int cmp_seg(const void *a, const void *b) { return ((const vox_seg *)a)->head - ((const vox_seg *)b)->head; }
+
+/* _simple_voxel_downsample: voxel = floor(p / size) per axis; one output per voxel in order of first appearance,
+ * = the mean of its points accumulated in input order */
+ORC_API int orc_voxel_downsample(const double *pts, int n, double voxel_size, double *out, int *n_out)
+{
+    vox_rec *rec = (vox_rec *)malloc(sizeof(vox_rec) * (size_t)(n > 0 ? n : 1));
+    vox_seg *seg = (vox_seg *)malloc(sizeof(vox_seg) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) rec[i].k[c] = (long long)floor(pts[3 * i + c] / voxel_size);
+        rec[i].idx = i;
+    }
+    qsort(rec, (size_t)n, sizeof(vox_rec), cmp_vox);
+    int ns = 0;
+    for (int i = 0; i < n; i++) {
+        if (i == 0 || rec[i].k[0] != rec[i - 1].k[0] || rec[i].k[1] != rec[i - 1].k[1] || rec[i].k[2] != rec[i - 1].k[2]) {
+            seg[ns].head = rec[i].idx; seg[ns].start = i; seg[ns].count = 0;
+            ns++;
+        }
+        seg[ns - 1].count++;
+    }
+    qsort(seg, (size_t)ns, sizeof(vox_seg), cmp_seg);
+    for (int s = 0; s < ns; s++) {
+        double acc[3] = {0., 0., 0.};
+        for (int j = 0; j < seg[s].count; j++) {
+            const double *p = pts + 3 * (size_t)rec[seg[s].start + j].idx;
+            if (j == 0) { acc[0] = p[0]; acc[1] = p[1]; acc[2] = p[2]; }
+            else { acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; }
+        }
+        for (int c = 0; c < 3; c++) out[3 * s + c] = acc[c] / (double)seg[s].count;
+    }
+    *n_out = ns;
+    free(rec); free(seg);
+    return 0;
+}
+
+/* the k smallest Euclidean distances from point i to the cloud (itself included), ascending; brute force */
+static void knn_dists(const double *pts, int n, int i, int k, double *best)
+{
+    int m = 0;
+    for (int j = 0; j < n; j++) {
+        double s = 0.;
+        for (int c = 0; c < 3; c++) { const double d = pts[3 * i + c] - pts[3 * j + c]; s += d * d; }
+        if (m < k || s < best[m - 1]) {
+            int p = m < k ? m++ : k - 1;
+            while (p > 0 && best[p - 1] > s) { best[p] = best[p - 1]; p--; }
+            best[p] = s;
+        }
+    }
+    for (int j = 0; j < m; j++) best[j] = sqrt(best[j]);
+}
+
+/* _simple_outlier_removal: the predicate mean < mean + ratio * std of the nb nearest-neighbour distances */
+ORC_API int orc_sor_simple(const double *pts, int n, int nb_neighbors, double std_ratio, double *out, int *n_out)
+{
+    if (n < nb_neighbors) { memcpy(out, pts, sizeof(double) * 3 * (size_t)n); *n_out = n; return 0; }
+    const int k = nb_neighbors + 1 < n ? nb_neighbors + 1 : n;   /* cKDTree pads missing neighbours with inf */
+    double *best = (double *)malloc(sizeof(double) * (size_t)(nb_neighbors + 1)), *dev = (double *)malloc(sizeof(double) * (size_t)(nb_neighbors + 1));
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        knn_dists(pts, n, i, k, best);
+        for (int j = k; j < nb_neighbors + 1; j++) best[j] = INFINITY;
+        const double *d = best + 1;
+        const double mean = np_pairwise_sum(d, (size_t)nb_neighbors) / (double)nb_neighbors;
+        for (int j = 0; j < nb_neighbors; j++) { const double x = d[j] - mean; dev[j] = x * x; }
+        const double sd = sqrt(np_pairwise_sum(dev, (size_t)nb_neighbors) / (double)nb_neighbors);
+        if (mean < (mean + std_ratio * sd)) { memcpy(out + 3 * (size_t)m, pts + 3 * (size_t)i, 24); m++; }
+    }
+    *n_out = m;
+    free(best); free(dev);
+    return 0;
+}
+
+/* avg_point_spacing of compute_point_cloud_metrics: np.mean of the nearest-neighbour distances */
+ORC_API double orc_avg_point_spacing(const double *pts, int n)
+{
+    double *nn = (double *)malloc(sizeof(double) * (size_t)n), best[2];
+    for (int i = 0; i < n; i++) { knn_dists(pts, n, i, 2, best); nn[i] = best[1]; }
+    const double r = np_pairwise_sum(nn, (size_t)n) / (double)n;
+    free(nn);
+    return r;
+}

@@ -394,3 +394,28 @@ def laser_depth_map(uv, disp: np.ndarray, Q) -> np.ndarray:
     out = np.empty((h, w), np.float32)
     lib().orc_laser_depth_map(_p(uv, C.c_double), len(uv), disp.ctypes.data_as(C.c_void_p), int(is64), w, h, _p(q, C.c_double), _p(out, C.c_float))
     return out
+
+
+def voxel_downsample(points: np.ndarray, voxel_size: float) -> np.ndarray:
+    """PointCloudProcessor._simple_voxel_downsample (utils/point_cloud.py:55-79)."""
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    out = np.empty((max(len(p), 1), 3), np.float64)
+    n = C.c_int(0)
+    lib().orc_voxel_downsample(_p(p, C.c_double), len(p), C.c_double(voxel_size), _p(out, C.c_double), C.byref(n))
+    return out[: n.value].copy()
+
+
+def sor_simple(points: np.ndarray, nb_neighbors: int = 20, std_ratio: float = 2.0) -> np.ndarray:
+    """PointCloudProcessor._simple_outlier_removal behind statistical_outlier_removal (utils/point_cloud.py:81-132)."""
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    out = np.empty((max(len(p), 1), 3), np.float64)
+    n = C.c_int(0)
+    lib().orc_sor_simple(_p(p, C.c_double), len(p), int(nb_neighbors), C.c_double(std_ratio), _p(out, C.c_double), C.byref(n))
+    return out[: n.value].copy()
+
+
+def avg_point_spacing(points: np.ndarray) -> float:
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    f = lib().orc_avg_point_spacing
+    f.restype = C.c_double
+    return float(f(_p(p, C.c_double), len(p)))

@@ -677,3 +677,46 @@ def test_disparity_triangulation_matches_reference_golden_and_oracle(gpu, O, gol
     assert np.array_equal(r.create_laser_depth_map(pts, disp, (H, W)), O.laser_depth_map(pts, disp, Q))
     l2, r2 = fix_roi_alignment(lb, rb, (3, 2, 600, 350), (10, 0, 620, 340))
     assert l2.shape == (338, 593, 3) and np.array_equal(r2, rb[2:340, 10:603])
+
+
+def test_pointcloud_processor_matches_reference_golden(gpu, O, tmp_path):
+    """PointCloudProcessor on the GPU: bit-identical to the reference's own outputs (golden vectors, including points of
+    the cloud the reference ships) and to the oracle on a larger seeded cloud; PLY text byte for byte."""
+    import os
+    from laser_3d_reconstruction_amd.utils.point_cloud import PointCloudProcessor
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pointcloud_golden.npz"))
+    proc = PointCloudProcessor()
+    for name in ["real", "dense", "grid", "dup", "neg", "few", "line", "nb1"]:
+        pts = g[name + "_in"]
+        voxel, nb, ratio = g[name + "_params"]
+        assert np.array_equal(proc.voxel_downsample(pts, voxel), g[name + "_voxel"]), name
+        assert np.array_equal(np.asarray(proc.statistical_outlier_removal(pts, int(nb), ratio)).reshape(-1, 3), g[name + "_sor"]), name
+        m = proc.compute_point_cloud_metrics(pts)
+        got = np.concatenate([m["center"], m["std"], m["min"], m["max"], m["dimensions"], [m["volume"], m["avg_point_spacing"]]])
+        assert np.array_equal(got, g[name + "_metrics"]), name
+    real, dense = g["real_in"], g["dense_in"]
+    merged = proc.merge_and_clean([real[:1000], np.zeros((0, 3)), dense[:1000], real[500:1500]], 0.004)
+    assert np.array_equal(merged, g["merge_out"])
+    assert proc.merge_and_clean([]).shape == (0,) and proc.voxel_downsample(np.zeros((0, 3))).shape == (0, 3)
+    # a larger cloud against the oracle
+    rng = np.random.default_rng(8)
+    big = np.concatenate([rng.normal(0, 0.05, (20000, 3)) + [0, 0, 0.6], rng.uniform(-0.3, 0.3, (5000, 3))])
+    assert np.array_equal(proc.voxel_downsample(big, 0.004), O.voxel_downsample(big, 0.004))
+    sub = big[:6000]
+    assert np.array_equal(proc.statistical_outlier_removal(sub, 20, 2.0), O.sor_simple(sub, 20, 2.0))
+    assert proc.compute_point_cloud_metrics(sub)["avg_point_spacing"] == O.avg_point_spacing(sub)
+    with pytest.raises(gpu.L3DError):
+        proc.voxel_downsample(np.array([[0.0, 0, 0], [1e30, 0, 0]]), 1e-9)
+    # PLY writers
+    f = str(tmp_path / "cloud.ply")
+    proc.save_ply(real[:5], f, colors=np.array([[0, 255, 0], [1, 2, 3], [255, 255, 255], [9.7, 0.2, 200.9], [0, 0, 0]]))
+    assert open(f, "rb").read() == g["ply_text"].tobytes()
+    proc.save_ply(g["neg_in"][:3] * 1e3, str(tmp_path / "nocolor"))
+    assert open(str(tmp_path / "nocolor.ply"), "rb").read() == g["ply_text_nocolor"].tobytes()
+    fb = str(tmp_path / "bin.ply")
+    proc.save_ply_binary(real[:7], fb, colors=np.full((7, 3), [0, 255, 0]))
+    raw = open(fb, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"format binary_little_endian 1.0" in head and b"property double x" in head and b"element vertex 7" in head
+    assert len(body) == 7 * 27 and np.array_equal(np.frombuffer(body[:24], "<f8"), real[0])

@@ -318,3 +318,17 @@ def test_disparity_triangulation_matches_reference_golden(O, golden):
         assert np.array_equal(O.laser_depth_map(c["uv"], d, c["Q"]).astype(np.float64), np.array(c["laser_depth"]))
         n += len(a) + len(b)
     assert n > 500
+
+
+def test_pointcloud_oracle_matches_reference_golden(O):
+    """Voxel downsampling, the outlier filter and the spacing metric of the oracle against PointCloudProcessor itself
+    (vectors generated by importing the reference, tests/golden/make_pointcloud_golden.py): bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pointcloud_golden.npz"))
+    for name in ["real", "dense", "grid", "dup", "neg", "few", "line", "nb1"]:
+        pts = g[name + "_in"]
+        voxel, nb, ratio = g[name + "_params"]
+        assert np.array_equal(O.voxel_downsample(pts, voxel), g[name + "_voxel"]), name
+        assert np.array_equal(O.sor_simple(pts, int(nb), ratio), g[name + "_sor"]), name
+        assert O.avg_point_spacing(pts) == g[name + "_metrics"][-1], name
+    assert len(g["line_sor"]) == 2 and len(g["nb1_sor"]) == 0 and len(g["dense_voxel"]) < 1000
