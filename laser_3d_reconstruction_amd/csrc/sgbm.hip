@@ -8,8 +8,11 @@
 //                                 Birchfield-Tomasi half-pixel min/max, raw intensity and its min/max
 //   rrev   [B][6][H][W]   u8      the same six quantities of the right image as separate planes,
 //                                 mirrored in x so that increasing disparity = increasing address
-//   Cvol   [B][H][W1][D]  s16     block-aggregated matching cost of the stripe that owns the row
-//   Tvol   [B][H][W1][D]  s16     top->down path cost
+//   Tvol   [B][H+4][W1][D] s16    top->down path cost; row y of stripe n at y + n + 1, the row before a stripe's first own
+//                                 row = the path state entering it (path-only scheme, the default)
+//   Mvol   [B][H+4][W1]   u32     minimum over d of the same rows, in both halves
+//   Cvol, Tvol [B][H][W1][D] s16  aggregated cost and path cost, stored side by side instead, only when a cost of the
+//                                 top->down recurrence could saturate (block size >= 15 or P2 > 32767)
 //   ckpt   [B][H][ceil(W1/4)][D] s16  left->right path state at every segment start (checkpoints)
 //   wta    [B][H][W1]     u32     (biased min S << 16 | argmin) or 0xFFFFFFFF (uniqueness reject)
 //   dsub   [B][H][W1]     s16     sub-pixel disparity (x16) of the column
@@ -47,6 +50,12 @@ struct SgbmGeom {
     // (D = 2 * NP * LPP), chosen separately for the vertical and the horizontal kernel: the volumes
     // between them are plain [column][disparity] arrays either way
     int LPPv, NPv, LPPh, NPh;
+    // tonly: the aggregated-cost volume is not stored.  The vertical kernel writes the top->down path volume
+    // only, with the per-column minimum beside it, into HR = H + 4 rows per frame: row y of stripe n sits at
+    // y + n + 1 and the row before a stripe's first own row holds that stripe's path state entering it (zeros
+    // for stripe 0), so "the previous row" of every image row is always the row above it.  The horizontal
+    // kernel gets C back as T - (what the recurrence added), which is exact as long as nothing saturates.
+    int tonly, HR;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -273,7 +282,7 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
 template <int NP, int LPP>
 __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
-                                                       uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol)
+                                                       uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
     constexpr int GPB = 256 / LPP;          // image columns per block
     constexpr int NPS = LPP == 16 ? 3 : 2;  // tile columns per lane group: ceil((GPB + 20) / GPB), blockSize <= 21
@@ -433,8 +442,12 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 
     const uint32_t voff = (uint32_t)(((size_t)xc_own * CW + l * NP) * sizeof(uint32_t));
     const size_t row_bytes = (size_t)W1 * CW * sizeof(uint32_t);
-    char *Cout = reinterpret_cast<char *>(Cvol) + ((size_t)b * H + start) * row_bytes;
-    char *Tout = reinterpret_cast<char *>(Tvol) + ((size_t)b * H + start) * row_bytes;
+    // volume row of image row `start`: plain, or shifted by the stripe's padding rows
+    const size_t vrow = g.tonly ? (size_t)b * g.HR + start + n + 1 : (size_t)b * H + start;
+    const int first_stored = g.tonly ? own0 - 1 : own0;   // tonly also keeps the state entering the stripe's first own row
+    char *Cout = reinterpret_cast<char *>(Cvol) + vrow * row_bytes;
+    char *Tout = reinterpret_cast<char *>(Tvol) + vrow * row_bytes;
+    uint32_t *Mout = Mvol + vrow * W1 + xc_own;
     // ring slots (row index mod NR) of the row entering and the row leaving the vertical window
     int slot_add = (start + 1 + SH2) % NR, slot_sub = start % NR;
     const int slot_last = (H - 1) % NR;
@@ -450,15 +463,19 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         topMin = sgm_step<NP, LPP>(Cst, Tst, topMin, pen, first, last);
         if (box_now) stage_put(y & 1);
         if (fetch_next) stage_fetch(y + 2 + SH2);
-        if (y >= own0 && active) {
+        if (y >= first_stored && active) {
             Pack<NP> pc, pt;
 #pragma unroll
             for (int p = 0; p < NP; p++) { pc.v[p] = Cst[p]; pt.v[p] = Tst[p]; }
-            *reinterpret_cast<Pack<NP> *>(Cout + voff) = pc;
             *reinterpret_cast<Pack<NP> *>(Tout + voff) = pt;
+            if (g.tonly) {
+                if (first) *Mout = topMin;
+            } else
+                *reinterpret_cast<Pack<NP> *>(Cout + voff) = pc;
         }
         Cout += row_bytes;
         Tout += row_bytes;
+        Mout += W1;
         if (y + 1 < end) {
             if (box_now) {
                 box_row(slot_add, y & 1);
@@ -486,9 +503,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 // checkpoint into registers, then runs the right->left recurrence over the same columns.  All
 // loads are issued one segment ahead of their use.
 // ---------------------------------------------------------------------------------------------
-template <int NP>
+template <int NP, bool TONLY>
 struct SegLen {
-    static constexpr int value = NP <= 2 ? 8 : 4;
+    static constexpr int value = (NP <= 2 && !TONLY) ? 8 : 4; // TONLY prefetches three operands per column
 };
 
 // Winner-take-all and uniqueness test for one column from the summed costs S, on all lanes of the
@@ -561,12 +578,52 @@ __device__ __forceinline__ int subpixel_disp(const SgbmGeom &g, int best, int sm
     return dd + g.minD * 16;
 }
 
+// The aggregated cost of a column from the path volume: C = T - (min(P[d], P[d-1]+P1, P[d+1]+P1, minP+P2) - (minP+P2)),
+// P = the path costs of the row above, minP their minimum (both halves).  Exact when the recurrence never saturated.
 template <int NP, int LPP>
-__global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
-                                                   const uint32_t *__restrict__ Tvol, uint32_t *__restrict__ ckpt,
-                                                   uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
+__device__ __forceinline__ void cost_from_paths(const uint32_t (&T)[NP], const uint32_t (&P)[NP], uint32_t minP, const SgmPenalty &k, bool first,
+                                                bool last, uint32_t (&C)[NP])
 {
-    constexpr int SEG = SegLen<NP>::value;
+    const uint32_t BIG = 0x7fff7fffu;
+    const uint32_t mp2v = pk_adds(minP, k.P2a);
+    uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, P[NP - 1]);
+    uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, P[0]);
+    if (LPP < 16) {
+        below = first ? BIG : below;
+        above = last ? BIG : above;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const uint32_t lo_src = (p > 0) ? P[p - 1] : below;
+        const uint32_t hi_src = (p < NP - 1) ? P[p + 1] : above;
+        const uint32_t dm1 = __builtin_amdgcn_alignbit(P[p], lo_src, 16);
+        const uint32_t dp1 = __builtin_amdgcn_alignbit(hi_src, P[p], 16);
+        const uint32_t a = pk_adds(pk_min(dm1, dp1), k.P1v);
+        const uint32_t m = pk_min(a, pk_min(P[p], mp2v));
+        C[p] = pk_sub(T[p], pk_subs(m, mp2v));
+    }
+}
+
+// What the horizontal kernel fetches per column: the aggregated cost, or (TONLY) the path costs of the row and of
+// the row above plus the latter's minimum, from which the aggregated cost is rebuilt at the point of use.
+template <int NP, bool TONLY>
+struct ColIn;
+template <int NP>
+struct ColIn<NP, false> {
+    Pack<NP> c;
+};
+template <int NP>
+struct ColIn<NP, true> {
+    Pack<NP> t, p;
+    uint32_t m;
+};
+
+template <int NP, int LPP, bool TONLY>
+__global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
+                                                   const uint32_t *__restrict__ Tvol, const uint32_t *__restrict__ Mvol,
+                                                   uint32_t *__restrict__ ckpt, uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
+{
+    constexpr int SEG = SegLen<NP, TONLY>::value;
     constexpr int RPW = 64 / LPP; // image rows per wave
     constexpr int CW = NP * LPP;  // u32 per volume column
     constexpr int D = 2 * CW;
@@ -585,15 +642,47 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     const int nseg = (W1 + SEG - 1) / SEG;
     constexpr size_t col_bytes = (size_t)CW * sizeof(uint32_t);
     // block-uniform bases plus a fixed per-lane byte offset (row inside the block, lane inside the column)
-    const char *Cb = reinterpret_cast<const char *>(Cvol) + (size_t)row0 * W1 * col_bytes;
-    const char *Tb = reinterpret_cast<const char *>(Tvol) + (size_t)row0 * W1 * col_bytes;
+    // volume row of an image row (index over batch * H): plain, or with the stripe padding of the path-only layout
+    auto vol_row = [&](int row) -> size_t {
+        if (!TONLY) return (size_t)row;
+        const int b = row / g.H, y = row - b * g.H;
+        return (size_t)b * g.HR + y + y / g.stripe_sz + 1;
+    };
+    const size_t vrow0 = vol_row(row0) - (TONLY ? 1 : 0);       // uniform base row: one above the first row when the row above is read too
+    const size_t vrel = vol_row(row0 + grp_ld) - vrow0;         // this lane group's row relative to it
+    const char *Cb = reinterpret_cast<const char *>(Cvol) + vrow0 * W1 * col_bytes;
+    const char *Tb = reinterpret_cast<const char *>(Tvol) + vrow0 * W1 * col_bytes;
+    const char *Mb = reinterpret_cast<const char *>(Mvol) + vrow0 * W1 * sizeof(uint32_t);
     char *Kb = reinterpret_cast<char *>(ckpt) + (size_t)row0 * nseg * col_bytes;
-    const uint32_t voff = (uint32_t)(((size_t)grp_ld * W1 * CW + l * NP) * sizeof(uint32_t));
+    const uint32_t voff = (uint32_t)((vrel * W1 * CW + l * NP) * sizeof(uint32_t));
+    const uint32_t poff = voff - (uint32_t)(TONLY ? W1 * col_bytes : 0);       // the row above
+    const uint32_t moff = (uint32_t)((vrel - (TONLY ? 1 : 0)) * W1 * sizeof(uint32_t));
     const uint32_t koff = (uint32_t)(((size_t)grp_ld * nseg * CW + l * NP) * sizeof(uint32_t));
     const SgmPenalty pen = make_penalty(g);
     const int d0 = l * 2 * NP; // first disparity index held by this lane
-    auto ldC = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Cb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
     auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
+    auto fetch = [&](int x) {
+        const size_t xc = (size_t)min(max(x, 0), W1 - 1);
+        ColIn<NP, TONLY> r;
+        if constexpr (TONLY) {
+            r.t = *reinterpret_cast<const Pack<NP> *>(Tb + xc * col_bytes + voff);
+            r.p = *reinterpret_cast<const Pack<NP> *>(Tb + xc * col_bytes + poff);
+            r.m = *reinterpret_cast<const uint32_t *>(Mb + xc * sizeof(uint32_t) + moff);
+        } else
+            r.c = *reinterpret_cast<const Pack<NP> *>(Cb + xc * col_bytes + voff);
+        return r;
+    };
+    // aggregated cost of a fetched column, left in place (TONLY: rebuilt into the slot of the row above's costs)
+    auto cost = [&](ColIn<NP, TONLY> &r) -> const uint32_t(&)[NP] {
+        if constexpr (TONLY) {
+            uint32_t c[NP];
+            cost_from_paths<NP, LPP>(r.t.v, r.p.v, r.m, pen, first, last, c);
+#pragma unroll
+            for (int p = 0; p < NP; p++) r.p.v[p] = c[p];
+            return r.p.v;
+        } else
+            return r.c.v;
+    };
     // role of this lane in the per-segment step: column u of row e_grp
     const int e_u = tid % SEG, e_grp = tid / SEG;
     const bool e_on = tid < RPW * SEG && row0 + e_grp < nrows_total;
@@ -605,19 +694,19 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = 0;
     uint32_t mn = 0;
-    Pack<NP> cb[SEG], nb[SEG];
+    ColIn<NP, TONLY> cb[SEG], nb[SEG];
 #pragma unroll
-    for (int u = 0; u < SEG; u++) cb[u] = ldC(u);
+    for (int u = 0; u < SEG; u++) cb[u] = fetch(u);
     for (int j = 0; j < nseg; j++) {
         Pack<NP> o;
 #pragma unroll
         for (int p = 0; p < NP; p++) o.v[p] = st[p];
 #pragma unroll
-        for (int u = 0; u < SEG; u++) nb[u] = ldC((j + 1) * SEG + u);
+        for (int u = 0; u < SEG; u++) nb[u] = fetch((j + 1) * SEG + u);
         if (row_ok) *reinterpret_cast<Pack<NP> *>(Kb + (size_t)j * col_bytes + koff) = o;
 #pragma unroll
         for (int u = 0; u < SEG; u++)
-            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cb[u].v, st, mn, pen, first, last);
+            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cost(cb[u]), st, mn, pen, first, last);
 #pragma unroll
         for (int u = 0; u < SEG; u++) cb[u] = nb[u];
     }
@@ -627,14 +716,20 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
     for (int p = 0; p < NP; p++) rst[p] = 0;
     uint32_t rmn = 0;
-    Pack<NP> tb[SEG], ntb[SEG], fs, nfs;
+    Pack<NP> tb[TONLY ? 1 : SEG], ntb[TONLY ? 1 : SEG], fs, nfs; // TONLY: the row's path costs arrive with the column fetch
 #pragma unroll
-    for (int u = 0; u < SEG; u++) { cb[u] = ldC((nseg - 1) * SEG + u); tb[u] = ldT((nseg - 1) * SEG + u); }
+    for (int u = 0; u < SEG; u++) {
+        cb[u] = fetch((nseg - 1) * SEG + u);
+        if constexpr (!TONLY) tb[u] = ldT((nseg - 1) * SEG + u);
+    }
     fs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)(nseg - 1) * col_bytes + koff);
     for (int j = nseg - 1; j >= 0; j--) {
         const int jn = max(j - 1, 0);
 #pragma unroll
-        for (int u = 0; u < SEG; u++) { nb[u] = ldC(jn * SEG + u); ntb[u] = ldT(jn * SEG + u); }
+        for (int u = 0; u < SEG; u++) {
+            nb[u] = fetch(jn * SEG + u);
+            if constexpr (!TONLY) ntb[u] = ldT(jn * SEG + u);
+        }
         nfs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)jn * col_bytes + koff);
         // left -> right costs of this segment, recomputed from the checkpoint
         uint32_t fst[NP], mv = 0x7fff7fffu;
@@ -644,7 +739,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cb[u].v, fst, fmn, pen, first, last);
+            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cost(cb[u]), fst, fmn, pen, first, last);
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
@@ -652,10 +747,13 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         for (int u = SEG - 1; u >= 0; u--) {
             const int xc = j * SEG + u;
             if (xc < W1) {
-                rmn = sgm_step<NP, LPP>(cb[u].v, rst, rmn, pen, first, last);
+                // (TONLY: cost() already ran on this column in the loop above and left C in place)
+                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return cb[u].p.v; else return cb[u].c.v; }();
+                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return cb[u].t.v; else return tb[u].v; }();
+                rmn = sgm_step<NP, LPP>(cu, rst, rmn, pen, first, last);
                 Pack<NP> S;
 #pragma unroll
-                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tb[u].v[p]);
+                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
                 const uint32_t key = wta_key<NP, LPP>(g, S.v, d0);
                 *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
                 if (first) sK[grp * SEG + u] = key;
@@ -679,7 +777,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         }
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < SEG; u++) { cb[u] = nb[u]; tb[u] = ntb[u]; }
+        for (int u = 0; u < SEG; u++) {
+            cb[u] = nb[u];
+            if constexpr (!TONLY) tb[u] = ntb[u];
+        }
         fs = nfs;
     }
 }
@@ -979,9 +1080,14 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     g->stripe_overlap = (g->SH2 + 1) + (int)std::ceil(0.1 * g->stripe_sz);
     g->speckleWindowSize = p->speckleWindowSize;
     g->speckleRange = p->speckleRange;
-    // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; the
-    // vertical kernel gains from that up to 64 disparities.  The horizontal kernel has one lane
-    // group per image row, so wider groups mean more waves in flight, which it needs more.
+    // no saturation anywhere in the top->down recurrence: 0 <= C <= 32767 and P2 <= 32767
+    const long long max_c = (long long)(2 * g->SW2 + 1) * (2 * g->SH2 + 1) * (2 * g->ftzero + 63);
+    g->tonly = g->P2 <= 32767 && max_c <= 32767;
+    if (const char *ov = std::getenv("L3D_SGBM_TONLY"))
+        if (std::atoi(ov) == 0) g->tonly = 0;
+    // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; both kernels gain from
+    // that up to 64 disparities -- the horizontal one only in the path-only scheme, where it is bound by vector
+    // instructions; with both volumes it is bound by memory stalls and needs the wave count of 16 lanes per row.
     // L3D_SGBM_LPPV / L3D_SGBM_LPPH = 8|16 override the choice (experiments).
     auto pick = [&](const char *name, int dflt) {
         int lpp = dflt;
@@ -992,9 +1098,10 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
         return lpp;
     };
     g->LPPv = pick("L3D_SGBM_LPPV", g->D <= 64 ? 8 : 16);
-    g->LPPh = pick("L3D_SGBM_LPPH", 16);
+    g->LPPh = pick("L3D_SGBM_LPPH", (g->D <= 64 && g->tonly) ? 8 : 16);
     g->NPv = g->D / (2 * g->LPPv);
     g->NPh = g->D / (2 * g->LPPh);
+    g->HR = g->H + 4;
     return 0;
 }
 
@@ -1026,7 +1133,7 @@ struct l3d_sgbm {
     int16_t *out_disp = nullptr;
     uint2 *lrec = nullptr;
     uint8_t *rrev = nullptr;
-    uint32_t *Cvol = nullptr, *Tvol = nullptr, *Lvol = nullptr, *wta = nullptr;
+    uint32_t *Cvol = nullptr, *Tvol = nullptr, *Mvol = nullptr, *Lvol = nullptr, *wta = nullptr;
     int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
     int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr, *pend = nullptr;
     size_t lds_vertical = 0;
@@ -1071,7 +1178,7 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     if (!h) return;
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Lvol,
+    void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol, h->Lvol,
                     h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -1145,8 +1252,14 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     alloc((void **)&h->out_disp, B * px * 2);
     alloc((void **)&h->lrec, B * px * sizeof(uint2));
     alloc((void **)&h->rrev, B * px * 6 + 1024); // the row staging reads whole words past the last needed byte
-    alloc((void **)&h->Cvol, vol);
-    alloc((void **)&h->Tvol, vol);
+    if (g.tonly) {
+        // path-only layout: no aggregated-cost volume, H + 4 rows per frame, the per-column path minimum beside it
+        alloc((void **)&h->Tvol, g.W1 > 0 ? B * g.HR * (size_t)g.W1 * g.D * sizeof(int16_t) : 0);
+        alloc((void **)&h->Mvol, g.W1 > 0 ? B * g.HR * (size_t)g.W1 * sizeof(uint32_t) : 0);
+    } else {
+        alloc((void **)&h->Cvol, vol);
+        alloc((void **)&h->Tvol, vol);
+    }
     alloc((void **)&h->Lvol, g.W1 > 0 ? B * height * (size_t)cdiv(g.W1, 4) * g.D * sizeof(int16_t) : 0);
     alloc((void **)&h->wta, cols * 4);
     alloc((void **)&h->dsub, cols * 2);
@@ -1187,7 +1300,7 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
-    hipLaunchKernelGGL((k_cost_vertical<NP, LPP>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol);
+    hipLaunchKernelGGL((k_cost_vertical<NP, LPP>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
 }
 
 template <int NP, int LPP>
@@ -1195,7 +1308,10 @@ static void launch_horizontal(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     const int nrows = B * g.H;
-    hipLaunchKernelGGL((k_horizontal<NP, LPP>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Lvol, h->wta, h->dsub);
+    if (g.tonly)
+        hipLaunchKernelGGL((k_horizontal<NP, LPP, true>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
+    else
+        hipLaunchKernelGGL((k_horizontal<NP, LPP, false>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
 }
 
 // 3x3 median of h->raw into d_disp, then the speckle filter in place: the tail of StereoSGBM::compute
@@ -1319,6 +1435,33 @@ extern "C" int l3d_sgbm_postfilter(l3d_sgbm *h, const int16_t *raw, int batch, i
     return L3D_OK;
 }
 
+// Host-side rebuild of the stage volumes from the path-only layout (stage-level checks only): T rows are
+// gathered out of the padded volume; C = T - (what the recurrence added from the row above), in plain integers.
+static void tonly_unpack(const SgbmGeom &g, const std::vector<int16_t> &padded, int B, int stage, int16_t *dst)
+{
+    const size_t col = (size_t)g.D, row = (size_t)g.W1 * col;
+    const int P1 = std::min(g.P1, 32767);
+    for (int b = 0; b < B; b++)
+        for (int y = 0; y < g.H; y++) {
+            const size_t r = (size_t)b * g.HR + y + y / g.stripe_sz + 1;
+            const int16_t *T = padded.data() + r * row, *P = T - row;
+            int16_t *o = dst + ((size_t)b * g.H + y) * row;
+            if (stage == 1) { std::memcpy(o, T, row * sizeof(int16_t)); continue; }
+            for (int x = 0; x < g.W1; x++) {
+                const int16_t *t = T + x * col, *p = P + x * col;
+                int minp = 32767;
+                for (int d = 0; d < g.D; d++) minp = std::min(minp, (int)p[d]);
+                const int mp2 = std::min(minp + g.P2, 32767);
+                for (int d = 0; d < g.D; d++) {
+                    const int l = d > 0 ? p[d - 1] : 32767, r2 = d < g.D - 1 ? p[d + 1] : 32767;
+                    const int a = std::min(std::min(l, r2) + P1, 32767);
+                    const int m = std::min(a, std::min((int)p[d], mp2));
+                    o[x * col + d] = (int16_t)(t[d] - std::max(m - mp2, -32768));
+                }
+            }
+        }
+}
+
 extern "C" int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size_t bytes)
 {
     L3D_REQUIRE(h && host_dst, "l3d_sgbm_fetch_stage: null argument");
@@ -1338,6 +1481,13 @@ extern "C" int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size
     DeviceGuard dg(h->device);
     L3D_HIP_CHECK(hipStreamSynchronize(h->stream));
     L3D_HIP_CHECK(hipDeviceSynchronize());
+    if (g.tonly && stage != 2) {
+        L3D_REQUIRE(bytes == avail, "l3d_sgbm_fetch_stage: the path-only layout returns whole stages (%zu bytes)", avail);
+        std::vector<int16_t> padded(B * g.HR * (size_t)g.W1 * g.D);
+        L3D_HIP_CHECK(hipMemcpy(padded.data(), h->Tvol, padded.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+        tonly_unpack(g, padded, (int)B, stage, (int16_t *)host_dst);
+        return L3D_OK;
+    }
     L3D_HIP_CHECK(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
     return L3D_OK;
 }

@@ -64,6 +64,8 @@ def test_gray_bit_exact(gpu, O):
     (333, 131, 64, 3, 0, dict(uniquenessRatio=5, speckleWindowSize=40, speckleRange=2)),  # ragged sizes
     (200, 64, 32, 7, 16, dict(uniquenessRatio=15, disp12MaxDiff=2)),   # positive minDisparity
     (160, 48, 32, 1, 0, dict(P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=-1, preFilterCap=0)),  # defaults applied
+    (240, 160, 32, 15, 0, {}),                                         # block 15: costs may pass 32767 -> both volumes are stored
+    (240, 160, 64, 19, 0, {}),                                         # block 19: P2 = 34656 > 32767 as well
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
@@ -83,6 +85,22 @@ def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     assert np.array_equal(got, dbg.disp), "final disparity"
     assert got.dtype == np.int16 and got.shape == (H, W)
     assert (got[:, :max(mind + D, 0)] == (mind - 1) * 16).all()
+
+
+def test_sgbm_two_volume_path_bit_exact(gpu, O, monkeypatch):
+    """The matcher normally stores the path volume only and rebuilds the aggregated cost; the layout with both volumes
+    (used when a cost could saturate) is forced here on the headline configuration."""
+    monkeypatch.setenv("L3D_SGBM_TONLY", "0")
+    W, H, D, b = 640, 360, 64, 5
+    kw = _ref_ctor(D, b)
+    lb, rb = _pair(W, H, D, 5)
+    gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+    m = _sgbm(**kw)
+    got = m.compute(gl, gr)
+    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), gl, gr)
+    assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C)
+    assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.T)
+    assert np.array_equal(got, dbg.disp)
 
 
 def test_sgbm_known_answer_constant_shift(gpu):
