@@ -254,8 +254,8 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
 }
 
 // LDS footprint of the vertical kernel in u32 words: two input stages, the pixel-cost tile, the ring
-// one stage = 4 byte-shifted copies of the 6 right-image plane runs + the left records; `roles` = words fetched per row
-__host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + 2 * tileC; }
+// one stage = 4 byte-shifted copies of the 6 right-image plane runs + the left records; `roles` = 8-byte fetches per row
+__host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + tileC; }
 // words between two shifted copies: at least the 6 plane runs, and 16 modulo 64 so that the lane groups of
 // a wave, which read from all four copies at once, spread over all 64 LDS banks
 __host__ __device__ inline int vertical_copy_stride(int tileC, int D)
@@ -269,6 +269,9 @@ __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, i
     const int tileC = 256 / LPP + 2 * SW2;
     return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (size_t)(2 * SH2 + 2) * 256 * NP;
 }
+struct __attribute__((packed, aligned(1))) UnalignedPair {
+    uint32_t lo, hi;
+};
 constexpr int kStageLoadsMax = 3; // staging words per thread and row (host checks the bound)
 
 // The inputs of an image row reach the lanes through LDS: the block needs tileC left records and,
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int NR = 2 * SH2 + 2;
     const int tileC = GPB + 2 * SW2;
     const int nd = (tileC - 1 + g.D + 3) / 4 + 1;   // u32 words per staged right-image plane
-    const int nroles = 6 * nd + 2 * tileC;          // = vertical_stage_roles(tileC, D)
+    const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
     const int cstride = vertical_copy_stride(tileC, g.D);
     const int stageW = 4 * cstride + 2 * tileC;     // = vertical_stage_words(tileC, D)
     uint32_t *stage = smem;                         // [2][ 4 shifts [cstride >= 6 planes [nd]] | tileC records [2] ]
@@ -318,6 +321,8 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int x_hi = tile_x(tileC - 1);
     const int rr_lo = W - 1 - x_hi + g.minD;        // mirrored index of the first staged right-image byte
     // staging roles of this thread: which global word goes to which stage word
+    // staging roles of this thread: every role fetches 8 bytes -- a word of a right-image plane run and the word after
+    // it (to cut the four shifted copies from), or one left record
     uint32_t s_goff[kStageLoadsMax], s_lidx[kStageLoadsMax];
     bool s_left[kStageLoadsMax], s_on[kStageLoadsMax];
 #pragma unroll
@@ -325,15 +330,10 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         const int i = min(tid + 256 * e, nroles - 1);
         s_on[e] = tid + 256 * e < nroles;
         s_left[e] = i >= 6 * nd;
-        if (s_left[e]) {
-            const int w = i - 6 * nd;
-            s_lidx[e] = (uint32_t)(4 * cstride + w);
-            s_goff[e] = (uint32_t)tile_x(w >> 1) * (uint32_t)sizeof(uint2) + (uint32_t)(w & 1) * 4u;
-        } else {
-            const int j = i / nd, idx = i - j * nd;
-            s_lidx[e] = (uint32_t)i;   // word of the unshifted copy; copy s lies s * cstride words further
-            s_goff[e] = (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
-        }
+        const int w = i - 6 * nd;                    // left: tile column
+        const int j = i / nd, idx = i - j * nd;      // right: plane, word
+        s_lidx[e] = s_left[e] ? (uint32_t)(4 * cstride + 2 * w) : (uint32_t)i; // copy s lies s * cstride words further
+        s_goff[e] = s_left[e] ? (uint32_t)tile_x(w) * (uint32_t)sizeof(uint2) : (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
     }
     // byte offset inside a staged plane of the first disparity this lane needs, per tile column
     uint32_t qword[NPS]; // as a word index into the stage: copy (offset & 3), word (offset >> 2)
@@ -347,34 +347,33 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 #pragma unroll
     for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = 0; }
     uint32_t topMin = 0;
-    uint32_t sreg[kStageLoadsMax][2];
+    uint32_t sreg_lo[kStageLoadsMax], sreg_hi[kStageLoadsMax];
 
-    auto stage_fetch = [&](int k) {
+    auto stage_fetch = [&](int k) __attribute__((always_inline)) {
         const char *lrow = lrec_b + (size_t)k * W * sizeof(uint2);
         const char *rrow = reinterpret_cast<const char *>(rrev_b + (size_t)k * W);
 #pragma unroll
         for (int e = 0; e < kStageLoadsMax; e++) {
             if (e * 256 < nroles && s_on[e]) {
-                if (s_left[e]) {
-                    sreg[e][0] = *reinterpret_cast<const uint32_t *>(lrow + s_goff[e]);
-                } else {
-                    uint32_t v[2];
-                    __builtin_memcpy(v, rrow + s_goff[e], 8);
-                    sreg[e][0] = v[0]; sreg[e][1] = v[1];
-                }
+                const UnalignedPair v = *reinterpret_cast<const UnalignedPair *>((s_left[e] ? lrow : rrow) + s_goff[e]);
+                sreg_lo[e] = v.lo;
+                sreg_hi[e] = v.hi;
             }
         }
     };
-    auto stage_put = [&](int buf) {
+    auto stage_put = [&](int buf) __attribute__((always_inline)) {
         uint32_t *st = stage + buf * stageW;
 #pragma unroll
         for (int e = 0; e < kStageLoadsMax; e++) {
             if (e * 256 < nroles && s_on[e]) {
-                st[s_lidx[e]] = sreg[e][0];
-                if (!s_left[e]) {
-                    st[s_lidx[e] + cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 1);
-                    st[s_lidx[e] + 2 * cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 2);
-                    st[s_lidx[e] + 3 * cstride] = __builtin_amdgcn_alignbyte(sreg[e][1], sreg[e][0], 3);
+                const uint32_t lo = sreg_lo[e], hi = sreg_hi[e];
+                st[s_lidx[e]] = lo;
+                if (s_left[e]) {
+                    st[s_lidx[e] + 1] = hi;
+                } else {
+                    st[s_lidx[e] + cstride] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+                    st[s_lidx[e] + 2 * cstride] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+                    st[s_lidx[e] + 3 * cstride] = __builtin_amdgcn_alignbyte(hi, lo, 3);
                 }
             }
         }
@@ -382,7 +381,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     // pixel costs of the row staged in `buf` -> LDS tile -> horizontal box sum for this thread's column -> ring slot.
     // Barrier A separates the previous row's tile reads from this row's tile writes (and publishes the
     // stage written since the last barrier); barrier B publishes the tile.
-    auto box_row = [&](int slot, int buf) {
+    auto box_row = [&](int slot, int buf) __attribute__((always_inline)) {
         lds_barrier();
         const uint32_t *st = stage + buf * stageW;
 #pragma unroll
@@ -413,7 +412,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         }
         lds_barrier();
     };
-    auto box_sum = [&](int slot) {
+    auto box_sum = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < NP; p++) hs[p] = 0;
         for (int j = 0; j <= 2 * SW2; j++) {
