@@ -132,6 +132,50 @@ struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : (NP % 2 == 0 ? 8
     uint32_t v[NP];
 };
 
+// Raw buffer access: descriptor in scalar registers, per-lane byte offset, uniform byte offset.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base)
+{
+    // raw buffer (stride 0), range 2 GiB from `base`, default data format of the gfx9 family
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ Pack<NP> buf_load(BufRsrc r, uint32_t voff, uint32_t soff)
+{
+    Pack<NP> o;
+    int p = 0;
+#pragma unroll
+    for (; p + 4 <= NP; p += 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 4 * p, soff, 0);
+        o.v[p] = v.x; o.v[p + 1] = v.y; o.v[p + 2] = v.z; o.v[p + 3] = v.w;
+    }
+    if (p + 2 <= NP) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 4 * p, soff, 0);
+        o.v[p] = v.x; o.v[p + 1] = v.y;
+        p += 2;
+    }
+    if (p < NP) o.v[p] = __builtin_amdgcn_raw_buffer_load_b32(r, voff + 4 * p, soff, 0);
+    return o;
+}
+template <int NP>
+__device__ __forceinline__ void buf_store(const Pack<NP> &o, BufRsrc r, uint32_t voff, uint32_t soff)
+{
+    int p = 0;
+#pragma unroll
+    for (; p + 4 <= NP; p += 4) {
+        const u32x4 v = {o.v[p], o.v[p + 1], o.v[p + 2], o.v[p + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + 4 * p, soff, 0);
+    }
+    if (p + 2 <= NP) {
+        const u32x2 v = {o.v[p], o.v[p + 1]};
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + 4 * p, soff, 0);
+        p += 2;
+    }
+    if (p < NP) __builtin_amdgcn_raw_buffer_store_b32(o.v[p], r, voff + 4 * p, soff, 0);
+}
+
 // Penalties of the recurrence as packed int16 splats.  prevMin + P2 saturates at 32767 in the
 // recurrence; P2 itself may exceed 32767 (P2 = 96*blockSize^2 does from blockSize 19 on), so it
 // is applied as up to three saturating additions of non-negative parts, which equals
@@ -649,30 +693,32 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     };
     const size_t vrow0 = vol_row(row0) - (TONLY ? 1 : 0);       // uniform base row: one above the first row when the row above is read too
     const size_t vrel = vol_row(row0 + grp_ld) - vrow0;         // this lane group's row relative to it
-    const char *Cb = reinterpret_cast<const char *>(Cvol) + vrow0 * W1 * col_bytes;
-    const char *Tb = reinterpret_cast<const char *>(Tvol) + vrow0 * W1 * col_bytes;
-    const char *Mb = reinterpret_cast<const char *>(Mvol) + vrow0 * W1 * sizeof(uint32_t);
-    char *Kb = reinterpret_cast<char *>(ckpt) + (size_t)row0 * nseg * col_bytes;
+    // Every access is a buffer access: a block-uniform descriptor (base of the block's rows), a uniform byte offset
+    // of the column in a scalar register and a per-lane offset that never changes -- no vector ALU work on addresses.
+    const BufRsrc Cr = make_rsrc(reinterpret_cast<const char *>(Cvol) + (TONLY ? 0 : vrow0 * W1 * col_bytes));
+    const BufRsrc Tr = make_rsrc(reinterpret_cast<const char *>(Tvol) + vrow0 * W1 * col_bytes);
+    const BufRsrc Mr = make_rsrc(reinterpret_cast<const char *>(Mvol) + (TONLY ? vrow0 * W1 * sizeof(uint32_t) : 0));
+    const BufRsrc Kr = make_rsrc(reinterpret_cast<const char *>(ckpt) + (size_t)row0 * nseg * col_bytes);
     const uint32_t voff = (uint32_t)((vrel * W1 * CW + l * NP) * sizeof(uint32_t));
     const uint32_t poff = voff - (uint32_t)(TONLY ? W1 * col_bytes : 0);       // the row above
     const uint32_t moff = (uint32_t)((vrel - (TONLY ? 1 : 0)) * W1 * sizeof(uint32_t));
     const uint32_t koff = (uint32_t)(((size_t)grp_ld * nseg * CW + l * NP) * sizeof(uint32_t));
     const SgmPenalty pen = make_penalty(g);
     const int d0 = l * 2 * NP; // first disparity index held by this lane
-    auto ldT = [&](int x) { return *reinterpret_cast<const Pack<NP> *>(Tb + (size_t)min(max(x, 0), W1 - 1) * col_bytes + voff); };
-    auto fetch = [&](int x) {
-        const size_t xc = (size_t)min(max(x, 0), W1 - 1);
+    auto fetch = [&](int x) __attribute__((always_inline)) {
+        const uint32_t xc = (uint32_t)min(max(x, 0), W1 - 1);
         ColIn<NP, TONLY> r;
         if constexpr (TONLY) {
-            r.t = *reinterpret_cast<const Pack<NP> *>(Tb + xc * col_bytes + voff);
-            r.p = *reinterpret_cast<const Pack<NP> *>(Tb + xc * col_bytes + poff);
-            r.m = *reinterpret_cast<const uint32_t *>(Mb + xc * sizeof(uint32_t) + moff);
+            r.t = buf_load<NP>(Tr, voff, xc * (uint32_t)col_bytes);
+            r.p = buf_load<NP>(Tr, poff, xc * (uint32_t)col_bytes);
+            r.m = __builtin_amdgcn_raw_buffer_load_b32(Mr, moff, xc * (uint32_t)sizeof(uint32_t), 0);
         } else
-            r.c = *reinterpret_cast<const Pack<NP> *>(Cb + xc * col_bytes + voff);
+            r.c = buf_load<NP>(Cr, voff, xc * (uint32_t)col_bytes);
         return r;
     };
+    auto ldT = [&](int x) __attribute__((always_inline)) { return buf_load<NP>(Tr, voff, (uint32_t)min(max(x, 0), W1 - 1) * (uint32_t)col_bytes); };
     // aggregated cost of a fetched column, left in place (TONLY: rebuilt into the slot of the row above's costs)
-    auto cost = [&](ColIn<NP, TONLY> &r) -> const uint32_t(&)[NP] {
+    auto cost = [&](ColIn<NP, TONLY> &r) __attribute__((always_inline)) -> const uint32_t(&)[NP] {
         if constexpr (TONLY) {
             uint32_t c[NP];
             cost_from_paths<NP, LPP>(r.t.v, r.p.v, r.m, pen, first, last, c);
@@ -688,26 +734,37 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     uint32_t *wrow = wta + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
     int16_t *drow = dsub + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
 
+    // segment being consumed (A) and segment in flight (B)
+    struct Seg {
+        ColIn<NP, TONLY> c[SEG];
+        Pack<NP> t[TONLY ? 1 : SEG]; // !TONLY, sweep 2: the row's path costs
+        Pack<NP> ck;                 // sweep 2: left -> right state at the segment start
+    };
+    Seg A, B;
+
     // ---- sweep 1: left -> right, keep the state at every segment start ----
     uint32_t st[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = 0;
     uint32_t mn = 0;
-    ColIn<NP, TONLY> cb[SEG], nb[SEG];
+    auto fetch1 = [&](Seg &s, int j) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < SEG; u++) cb[u] = fetch(u);
-    for (int j = 0; j < nseg; j++) {
+        for (int u = 0; u < SEG; u++) s.c[u] = fetch(j * SEG + u);
+    };
+    auto run1 = [&](Seg &s, int j) __attribute__((always_inline)) {
         Pack<NP> o;
 #pragma unroll
         for (int p = 0; p < NP; p++) o.v[p] = st[p];
-#pragma unroll
-        for (int u = 0; u < SEG; u++) nb[u] = fetch((j + 1) * SEG + u);
-        if (row_ok) *reinterpret_cast<Pack<NP> *>(Kb + (size_t)j * col_bytes + koff) = o;
+        if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)j * (uint32_t)col_bytes);
 #pragma unroll
         for (int u = 0; u < SEG; u++)
-            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cost(cb[u]), st, mn, pen, first, last);
-#pragma unroll
-        for (int u = 0; u < SEG; u++) cb[u] = nb[u];
+            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cost(s.c[u]), st, mn, pen, first, last);
+    };
+    fetch1(A, 0);
+    for (int j = 0; j < nseg; j++) {
+        fetch1(B, j + 1);
+        run1(A, j);
+        A = B;
     }
 
     // ---- sweep 2: segments right -> left ----
@@ -715,30 +772,25 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
     for (int p = 0; p < NP; p++) rst[p] = 0;
     uint32_t rmn = 0;
-    Pack<NP> tb[TONLY ? 1 : SEG], ntb[TONLY ? 1 : SEG], fs, nfs; // TONLY: the row's path costs arrive with the column fetch
-#pragma unroll
-    for (int u = 0; u < SEG; u++) {
-        cb[u] = fetch((nseg - 1) * SEG + u);
-        if constexpr (!TONLY) tb[u] = ldT((nseg - 1) * SEG + u);
-    }
-    fs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)(nseg - 1) * col_bytes + koff);
-    for (int j = nseg - 1; j >= 0; j--) {
-        const int jn = max(j - 1, 0);
+    auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
+        const int jc = max(j, 0);
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            nb[u] = fetch(jn * SEG + u);
-            if constexpr (!TONLY) ntb[u] = ldT(jn * SEG + u);
+            s.c[u] = fetch(jc * SEG + u);
+            if constexpr (!TONLY) s.t[u] = ldT(jc * SEG + u);
         }
-        nfs = *reinterpret_cast<const Pack<NP> *>(Kb + (size_t)jn * col_bytes + koff);
+        s.ck = buf_load<NP>(Kr, koff, (uint32_t)jc * (uint32_t)col_bytes);
+    };
+    auto run2 = [&](Seg &s, int j) __attribute__((always_inline)) {
         // left -> right costs of this segment, recomputed from the checkpoint
         uint32_t fst[NP], mv = 0x7fff7fffu;
 #pragma unroll
-        for (int p = 0; p < NP; p++) { fst[p] = fs.v[p]; mv = pk_min(mv, fst[p]); }
+        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = pk_min(mv, fst[p]); }
         uint32_t fmn = group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cost(cb[u]), fst, fmn, pen, first, last);
+            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cost(s.c[u]), fst, fmn, pen, first, last);
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
@@ -747,8 +799,8 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
             const int xc = j * SEG + u;
             if (xc < W1) {
                 // (TONLY: cost() already ran on this column in the loop above and left C in place)
-                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return cb[u].p.v; else return cb[u].c.v; }();
-                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return cb[u].t.v; else return tb[u].v; }();
+                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
+                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
                 rmn = sgm_step<NP, LPP>(cu, rst, rmn, pen, first, last);
                 Pack<NP> S;
 #pragma unroll
@@ -775,12 +827,12 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
             }
         }
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < SEG; u++) {
-            cb[u] = nb[u];
-            if constexpr (!TONLY) tb[u] = ntb[u];
-        }
-        fs = nfs;
+    };
+    fetch2(A, nseg - 1);
+    for (int j = nseg - 1; j >= 0; j--) {
+        fetch2(B, j - 1);
+        run2(A, j);
+        A = B;
     }
 }
 
@@ -1085,7 +1137,7 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     if (const char *ov = std::getenv("L3D_SGBM_TONLY"))
         if (std::atoi(ov) == 0) g->tonly = 0;
     // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; both kernels gain from
-    // that up to 64 disparities -- the horizontal one only in the path-only scheme, where it is bound by vector
+    // that up to 96 disparities (measured: slower again at 128) -- the horizontal one only in the path-only scheme, where it is bound by vector
     // instructions; with both volumes it is bound by memory stalls and needs the wave count of 16 lanes per row.
     // L3D_SGBM_LPPV / L3D_SGBM_LPPH = 8|16 override the choice (experiments).
     auto pick = [&](const char *name, int dflt) {
@@ -1096,8 +1148,8 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
         }
         return lpp;
     };
-    g->LPPv = pick("L3D_SGBM_LPPV", g->D <= 64 ? 8 : 16);
-    g->LPPh = pick("L3D_SGBM_LPPH", (g->D <= 64 && g->tonly) ? 8 : 16);
+    g->LPPv = pick("L3D_SGBM_LPPV", g->D <= 96 ? 8 : 16);
+    g->LPPh = pick("L3D_SGBM_LPPH", (g->D <= 96 && g->tonly) ? 8 : 16);
     g->NPv = g->D / (2 * g->LPPv);
     g->NPh = g->D / (2 * g->LPPh);
     g->HR = g->H + 4;
