@@ -243,30 +243,94 @@ __device__ __forceinline__ void prefilter_px(const uint8_t *img, int W, int H, i
     raw = r0[x];
 }
 
+// The six per-pixel quantities of one image at (x, y) from the prefiltered values of x-1, x, x+1
+struct PixRec {
+    int gc, glo, ghi, rc, rlo, rhi;
+};
+__device__ __forceinline__ PixRec pix_rec(int x, int W, int gm, int gc, int gp, int rm, int rc, int rp)
+{
+    const int gl = x > 0 ? (gc + gm) / 2 : gc, gr = x < W - 1 ? (gc + gp) / 2 : gc;
+    const int rl = x > 0 ? (rc + rm) / 2 : rc, rr = x < W - 1 ? (rc + rp) / 2 : rc;
+    PixRec o;
+    o.gc = gc; o.glo = min(gc, min(gl, gr)); o.ghi = max(gc, max(gl, gr));
+    o.rc = rc; o.rlo = min(rc, min(rl, rr)); o.rhi = max(rc, max(rl, rr));
+    return o;
+}
+
+// One thread per 4 consecutive pixels of a row, both images.  Away from the image's left and right edge the
+// three rows are read as whole words and the results leave as two 16-byte stores (left records) and one
+// 4-byte store per right-image plane; the edge groups take the per-pixel path.
 __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
                                                    int W, int H, int ftzero, uint2 *__restrict__ lrec, uint8_t *__restrict__ rrev)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= W) return;
+    // groups of 4 pixels are numbered through the whole image so that no lane idles at the end of a row
+    const int ngx = (W + 3) / 4;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = gid / ngx, x0 = (gid - y * ngx) * 4, b = blockIdx.z;
+    if (y >= H) return;
     const size_t img_off = (size_t)b * W * H;
+    const size_t plane = (size_t)W * H;
+    const bool fast = x0 >= 4 && x0 + 8 <= W;
     for (int side = 0; side < 2; side++) {
         const uint8_t *img = (side == 0 ? left : right) + img_off;
-        int gm, rm, gc, rc, gp, rp;
-        prefilter_px(img, W, H, y, x, ftzero, gc, rc);
-        if (x > 0) prefilter_px(img, W, H, y, x - 1, ftzero, gm, rm); else { gm = gc; rm = rc; }
-        if (x < W - 1) prefilter_px(img, W, H, y, x + 1, ftzero, gp, rp); else { gp = gc; rp = rc; }
-        const int gl = x > 0 ? (gc + gm) / 2 : gc, gr = x < W - 1 ? (gc + gp) / 2 : gc;
-        const int rl = x > 0 ? (rc + rm) / 2 : rc, rr = x < W - 1 ? (rc + rp) / 2 : rc;
-        const int glo = min(gc, min(gl, gr)), ghi = max(gc, max(gl, gr));
-        const int rlo = min(rc, min(rl, rr)), rhi = max(rc, max(rl, rr));
-        if (side == 0) {
-            lrec[img_off + (size_t)y * W + x] = make_uint2((uint32_t)(gc | (glo << 8) | (ghi << 16)), (uint32_t)(rc | (rlo << 8) | (rhi << 16)));
+        PixRec rec[4];
+        if (fast) {
+            // bytes x0-4 .. x0+7 of the three rows; every pixel x0-1 .. x0+4 is an interior column
+            const uint8_t *r0 = img + (size_t)y * W, *rn = y > 0 ? r0 - W : r0, *rs = y < H - 1 ? r0 + W : r0;
+            uint32_t w0[3], wn[3], ws[3];
+            __builtin_memcpy(w0, r0 + x0 - 4, 12);
+            __builtin_memcpy(wn, rn + x0 - 4, 12);
+            __builtin_memcpy(ws, rs + x0 - 4, 12);
+            auto byte = [](const uint32_t (&w)[3], int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+            int g[6], r[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { // pixel x0 - 1 + k sits at byte k + 3
+                int v = (byte(w0, k + 4) - byte(w0, k + 2)) * 2 + byte(wn, k + 4) - byte(wn, k + 2) + byte(ws, k + 4) - byte(ws, k + 2);
+                v = v < -ftzero ? -ftzero : (v > ftzero ? ftzero : v);
+                g[k] = v + ftzero;
+                r[k] = byte(w0, k + 3);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) rec[i] = pix_rec(x0 + i, W, g[i], g[i + 1], g[i + 2], r[i], r[i + 1], r[i + 2]);
         } else {
-            const size_t plane = (size_t)W * H;
-            uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - x);
-            o[0] = (uint8_t)gc; o[plane] = (uint8_t)glo; o[2 * plane] = (uint8_t)ghi;
-            o[3 * plane] = (uint8_t)rc; o[4 * plane] = (uint8_t)rlo; o[5 * plane] = (uint8_t)rhi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = min(x0 + i, W - 1);
+                int gm, rm, gc, rc, gp, rp;
+                prefilter_px(img, W, H, y, x, ftzero, gc, rc);
+                if (x > 0) prefilter_px(img, W, H, y, x - 1, ftzero, gm, rm); else { gm = gc; rm = rc; }
+                if (x < W - 1) prefilter_px(img, W, H, y, x + 1, ftzero, gp, rp); else { gp = gc; rp = rc; }
+                rec[i] = pix_rec(x, W, gm, gc, gp, rm, rc, rp);
+            }
+        }
+        if (side == 0) {
+            uint2 *o = lrec + img_off + (size_t)y * W + x0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x0 + i < W)
+                    o[i] = make_uint2((uint32_t)(rec[i].gc | (rec[i].glo << 8) | (rec[i].ghi << 16)), (uint32_t)(rec[i].rc | (rec[i].rlo << 8) | (rec[i].rhi << 16)));
+        } else {
+            // mirrored in x: pixels x0 .. x0+3 land on bytes W-1-x0 down to W-4-x0
+            uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - x0);
+            if (x0 + 4 <= W) {
+                const uint32_t q[6] = {
+                    (uint32_t)(rec[3].gc | (rec[2].gc << 8) | (rec[1].gc << 16) | (rec[0].gc << 24)),
+                    (uint32_t)(rec[3].glo | (rec[2].glo << 8) | (rec[1].glo << 16) | (rec[0].glo << 24)),
+                    (uint32_t)(rec[3].ghi | (rec[2].ghi << 8) | (rec[1].ghi << 16) | (rec[0].ghi << 24)),
+                    (uint32_t)(rec[3].rc | (rec[2].rc << 8) | (rec[1].rc << 16) | (rec[0].rc << 24)),
+                    (uint32_t)(rec[3].rlo | (rec[2].rlo << 8) | (rec[1].rlo << 16) | (rec[0].rlo << 24)),
+                    (uint32_t)(rec[3].rhi | (rec[2].rhi << 8) | (rec[1].rhi << 16) | (rec[0].rhi << 24))};
+#pragma unroll
+                for (int j = 0; j < 6; j++) __builtin_memcpy(o - 3 + j * plane, &q[j], 4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x0 + i < W) {
+                        uint8_t *oi = o - i;
+                        oi[0] = (uint8_t)rec[i].gc; oi[plane] = (uint8_t)rec[i].glo; oi[2 * plane] = (uint8_t)rec[i].ghi;
+                        oi[3 * plane] = (uint8_t)rec[i].rc; oi[4 * plane] = (uint8_t)rec[i].rlo; oi[5 * plane] = (uint8_t)rec[i].rhi;
+                    }
+            }
         }
     }
 }
@@ -1419,7 +1483,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
         if (slot >= 0) (void)hipEventRecord(h->ev[slot][mark++], s);
     };
     stamp();
-    hipLaunchKernelGGL(k_prefilter, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
+    hipLaunchKernelGGL(k_prefilter, dim3(cdiv(cdiv(g.W, 4) * g.H, 256), 1, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
     const bool have_v = dispatch_variant(g.NPv, g.LPPv, [&](auto np, auto lpp) { launch_vertical<decltype(np)::value, decltype(lpp)::value>(h, B, s); });
     stamp();
