@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 64 for C3, 16 for C5)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
     from laser_3d_reconstruction_amd.utils import synthetic as S
 
     W, H, D, block, use_wls, lam, sigma = CONFIGS[args.config]
-    B = args.batch
+    B = args.batch if args.batch else {"C2": 256, "C3": 64, "C5": 16}.get(args.config, 64)
 
     # start-up: rank 0 owns the calibration and broadcasts it (the only collective of the job)
     calib = dict(make_rig(W, H), Q=make_Q(W, H)) if rank == 0 else None
