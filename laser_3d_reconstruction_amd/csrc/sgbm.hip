@@ -989,7 +989,8 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
 //     continues into a component already known to be large; k_speckle_sum adds the pixel counts of
 //     the pending tile-level roots onto their final roots; k_speckle_apply erases what stayed small.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST = 64; // speckle tile edge = wave width: one ballot describes one tile row
+constexpr int ST = 64;  // speckle tile width = wave width: one ballot describes one tile row
+constexpr int STH = 32; // speckle tile height (32 rows keep the tile's LDS at 21 KB: six blocks per CU)
 
 __device__ __forceinline__ int lds_find(volatile int *L, int i)
 {
@@ -1036,22 +1037,30 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
                                                       int *__restrict__ labels, int *__restrict__ tsize, int *__restrict__ fsize,
                                                       int *__restrict__ pend_list, int *__restrict__ pend_count)
 {
-    __shared__ int lab[ST * ST];   // run head of a pixel; for run heads: union-find parent
-    __shared__ int cnt[ST * ST];   // at roots: pixel count, bit 31 = touches a shared tile edge
-    __shared__ short dv[ST * ST];
-    __shared__ unsigned long long rowL[ST]; // bit x: pixel x joins its left neighbour
+    __shared__ int lab[STH * ST];   // run head of a pixel; for run heads: union-find parent
+    __shared__ int cnt[STH * ST];   // at roots: pixel count, bit 31 = touches a shared tile edge
+    __shared__ short dv[STH * ST];
+    __shared__ unsigned long long rowL[STH]; // bit x: pixel x joins its left neighbour
     __shared__ int plist[256];
     __shared__ int pn, pbase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * ST;
+    const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * STH;
     const size_t img = (size_t)blockIdx.z * W * H;
     const int gx = tx0 + lane;
     if (tid == 0) pn = 0;
     const unsigned long long upto = (2ull << lane) - 1ull; // bits 0..lane
 
-    for (int rr = 0; rr < ST / 4; rr++) {
-        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
-        const int v = (gx < W && gy < H) ? (int)disp[img + (size_t)gy * W + gx] : newVal;
+    // all 16 rows of this wave are requested before the first one is used: one memory latency, not sixteen
+    int vrow[STH / 4];
+#pragma unroll
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int gy = ty0 + wv * (STH / 4) + rr;
+        vrow[rr] = (gx < W && gy < H) ? (int)disp[img + (size_t)gy * W + gx] : newVal;
+    }
+#pragma unroll
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, idx = y * ST + lane;
+        const int v = vrow[rr];
         const int vl = __shfl_up(v, 1);
         const bool valid = v != newVal;
         const bool joinL = valid && lane > 0 && vl != newVal && abs(v - vl) <= maxDiff;
@@ -1063,9 +1072,9 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         cnt[idx] = 0;
     }
     __syncthreads();
-    for (int rr = 0; rr < ST / 4; rr++) {
-        const int y = wv * (ST / 4) + rr, idx = y * ST + lane;
-        if (y + 1 >= ST) break;
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, idx = y * ST + lane;
+        if (y + 1 >= STH) break;
         const int v = dv[idx], vb = dv[idx + ST];
         const bool joinD = v != newVal && vb != newVal && abs(v - vb) <= maxDiff;
         const unsigned long long mD = __ballot(joinD);
@@ -1074,8 +1083,8 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         if ((need >> lane) & 1ull) lds_union(lab, lab[idx], lab[idx + ST]);
     }
     __syncthreads();
-    for (int rr = 0; rr < ST / 4; rr++) {
-        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
         const unsigned long long mL = rowL[y];
         const bool head = dv[idx] != newVal && !((mL >> lane) & 1ull);
         if (head) {
@@ -1084,13 +1093,13 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
             const int root = lds_find(lab, idx);
             lab[idx] = root;
             atomicAdd(&cnt[root], len);
-            const bool edge = (lane == 0 && tx0 > 0) || (lane + len == ST && tx0 + ST < W) || (y == 0 && ty0 > 0) || (y == ST - 1 && gy + 1 < H);
+            const bool edge = (lane == 0 && tx0 > 0) || (lane + len == ST && tx0 + ST < W) || (y == 0 && ty0 > 0) || (y == STH - 1 && gy + 1 < H);
             if (edge) atomicOr(&cnt[root], (int)0x80000000);
         }
     }
     __syncthreads();
-    for (int rr = 0; rr < ST / 4; rr++) {
-        const int y = wv * (ST / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
         if (gx >= W || gy >= H) continue;
         const size_t gi = img + (size_t)gy * W + gx;
         int out = -1;
@@ -1123,14 +1132,14 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
 __global__ void __launch_bounds__(256) k_speckle_border(const int16_t *__restrict__ disp, int W, int H, int B, int newVal, int maxDiff, int maxSize,
                                                         int *labels, int *tsize, int *fsize)
 {
-    const int nv = (W - 1) / ST, nh = (H - 1) / ST; // interior tile edges
+    const int nv = (W - 1) / ST, nh = (H - 1) / STH; // interior tile edges
     const int per_img = nv * H + nh * W;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)per_img * B) return;
     const int b = (int)(i / per_img), k = (int)(i % per_img);
     int xa, ya, step;
     if (k < nv * H) { xa = (k / H + 1) * ST - 1; ya = k % H; step = 1; }
-    else { const int k2 = k - nv * H; ya = (k2 / W + 1) * ST - 1; xa = k2 % W; step = W; }
+    else { const int k2 = k - nv * H; ya = (k2 / W + 1) * STH - 1; xa = k2 % W; step = W; }
     const size_t a = (size_t)b * W * H + (size_t)ya * W + xa, c = a + step;
     const int va = disp[a], vc = disp[c];
     if (va == newVal || vc == newVal || abs(va - vc) > maxDiff) return;
@@ -1384,7 +1393,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->labels, B * px * 4);
         alloc((void **)&h->sizes, B * px * 4);
         alloc((void **)&h->tsizes, B * px * 4);
-        alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, ST) * 256 + 1) * sizeof(int)); // [0] = count, then the list
+        alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, STH) * 256 + 1) * sizeof(int)); // [0] = count, then the list
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -1441,9 +1450,9 @@ static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &
     if (speckle) {
         const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
         const unsigned nb = (unsigned)((n + 255) / 256);
-        const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / ST) * g.W);
+        const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / STH) * g.W);
         L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, ST), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
+        hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, STH), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
                            h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend);
         if (pairs)
             hipLaunchKernelGGL(k_speckle_border, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, maxSize,
