@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
 // K6: speckle filter = connected components (4-neighbourhood, |a-b| <= maxDiff, pixels equal to
 // newVal excluded); components of at most maxSize pixels are set to newVal.
 // Only "is the component larger than maxSize" matters, so almost everything is decided inside a
-// 64x64 tile in LDS:
+// 64x32 tile in LDS:
 //   - rows are split into runs with one ballot per row (no atomics, no pointer chasing); union-find
 //     joins run heads of vertically adjacent rows, once per stretch of adjacent connected columns;
 //   - a tile-level component that does not touch an edge shared with another tile is complete: it is
