@@ -67,6 +67,7 @@ __device__ __forceinline__ uint32_t as_u32u(v2u a) { return __builtin_bit_cast(u
 __device__ __forceinline__ v2u as_v2u(uint32_t a) { return __builtin_bit_cast(v2u, a); }
 
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_v2s(a), as_v2s(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_v2s(a), as_v2s(b))); }
 __device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_add_sat(as_v2s(a), as_v2s(b))); }
 __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_sub_sat(as_v2s(a), as_v2s(b))); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u32(as_v2s(a) + as_v2s(b)); }
@@ -901,55 +902,91 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: single-map left-right consistency check; one block per image row
+// K4: single-map left-right consistency check; one block per image row.
+// The row is short, so what bounds this kernel is the latency of its dependent loads (key -> right
+// image column -> winner of that column).  Every thread therefore owns LR_ILP columns and issues the
+// loads of all of them, to clamped addresses, before it uses any.
 // ---------------------------------------------------------------------------------------------
+constexpr int LR_ILP = 4;
+constexpr int LR_THREADS = 64; // one wave per row: measured fastest, and the barriers cost nothing
+
 __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__restrict__ wta, const int16_t *__restrict__ dsub,
                                                  int16_t *__restrict__ raw)
 {
-    extern __shared__ uint32_t key2[]; // [W]
+    extern __shared__ uint32_t key2[]; // [W]: (cost, 0xffff - column) of the best left pixel that lands on a right column
     const int row = blockIdx.x; // over B*H
-    const int W = g.W, W1 = g.W1;
+    const int W = g.W, W1 = g.W1, bd = blockDim.x, tid = threadIdx.x;
     const uint32_t *w = wta + (size_t)row * W1;
     const int16_t *ds = dsub + (size_t)row * W1;
-    for (int x = threadIdx.x; x < W; x += blockDim.x) key2[x] = 0xffffffffu;
+    for (int x = tid; x < W; x += bd) key2[x] = 0xffffffffu;
     __syncthreads();
-    for (int xc = threadIdx.x; xc < W1; xc += blockDim.x) {
-        const uint32_t k = w[xc];
-        if (k == 0xffffffffu) continue;
-        const int best = (int)(k & 0xffffu);
-        const uint32_t cost = k >> 16;          // biased by 32768
-        if (cost == 65535u) continue;           // a cost of SHRT_MAX never beats the initial SHRT_MAX
-        const int x2 = xc + g.minX1 - best - g.minD;
-        if (x2 >= 0 && x2 < W) atomicMin(&key2[x2], (cost << 16) | (uint32_t)(0xffff - xc));
+    for (int base = 0; base < W1; base += LR_ILP * bd) {
+        uint32_t k[LR_ILP];
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            const int xc = base + i * bd + tid;
+            k[i] = w[min(xc, W1 - 1)];
+            if (xc >= W1) k[i] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            const int xc = base + i * bd + tid;
+            const int best = (int)(k[i] & 0xffffu);
+            const uint32_t cost = k[i] >> 16;   // biased by 32768; a cost of SHRT_MAX never beats the initial SHRT_MAX
+            const int x2 = xc + g.minX1 - best - g.minD;
+            if (cost != 65535u && x2 >= 0 && x2 < W) atomicMin(&key2[x2], (cost << 16) | (uint32_t)(0xffff - xc));
+        }
     }
     __syncthreads();
     int16_t *out = raw + (size_t)row * W;
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int val = g.invalid16;
-        if (x >= g.minX1 && x < g.maxX1) {
-            const int xc = x - g.minX1;
-            if (w[xc] != 0xffffffffu) {
-                const int d1 = ds[xc];
-                val = d1;
-                if (d1 != g.invalid16) {
-                    const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
-                    const int _x = x - _d, x_ = x - d_;
-                    bool c1 = false, c2 = false;
-                    if (_x >= 0 && _x < W) {
-                        const uint32_t k = key2[_x];
-                        const int v = (k == 0xffffffffu) ? g.invalid16 : (int)(w[0xffff - (int)(k & 0xffffu)] & 0xffffu) + g.minD;
-                        c1 = v >= g.minD && abs(v - _d) > g.disp12MaxDiff;
-                    }
-                    if (x_ >= 0 && x_ < W) {
-                        const uint32_t k = key2[x_];
-                        const int v = (k == 0xffffffffu) ? g.invalid16 : (int)(w[0xffff - (int)(k & 0xffffu)] & 0xffffu) + g.minD;
-                        c2 = v >= g.minD && abs(v - d_) > g.disp12MaxDiff;
-                    }
+    for (int base = 0; base < W; base += LR_ILP * bd) {
+        uint32_t kw[LR_ILP];
+        int d1[LR_ILP];
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            const int x = base + i * bd + tid;
+            const bool in = x >= g.minX1 && x < g.maxX1 && x < W;
+            const int xc = in ? x - g.minX1 : 0;
+            kw[i] = w[xc];
+            d1[i] = ds[xc];
+            if (!in) kw[i] = 0xffffffffu;
+        }
+        // the two right-image columns a sub-pixel disparity can land on, and what was recorded there
+        uint32_t ka[LR_ILP], kb[LR_ILP];
+        bool ina[LR_ILP], inb[LR_ILP];
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            const int x = base + i * bd + tid;
+            const int _x = x - (d1[i] >> 4), x_ = x - ((d1[i] + 15) >> 4);
+            ina[i] = _x >= 0 && _x < W;
+            inb[i] = x_ >= 0 && x_ < W;
+            ka[i] = key2[ina[i] ? _x : 0];
+            kb[i] = key2[inb[i] ? x_ : 0];
+        }
+        uint32_t wa[LR_ILP], wb[LR_ILP];
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            wa[i] = w[ka[i] == 0xffffffffu ? 0 : 0xffff - (int)(ka[i] & 0xffffu)];
+            wb[i] = w[kb[i] == 0xffffffffu ? 0 : 0xffff - (int)(kb[i] & 0xffffu)];
+        }
+#pragma unroll
+        for (int i = 0; i < LR_ILP; i++) {
+            const int x = base + i * bd + tid;
+            if (x >= W) continue;
+            int val = g.invalid16;
+            if (kw[i] != 0xffffffffu) {
+                val = d1[i];
+                if (val != g.invalid16) {
+                    const int _d = val >> 4, d_ = (val + 15) >> 4;
+                    const int va = ka[i] == 0xffffffffu ? g.invalid16 : (int)(wa[i] & 0xffffu) + g.minD;
+                    const int vb = kb[i] == 0xffffffffu ? g.invalid16 : (int)(wb[i] & 0xffffu) + g.minD;
+                    const bool c1 = ina[i] && va >= g.minD && abs(va - _d) > g.disp12MaxDiff;
+                    const bool c2 = inb[i] && vb >= g.minD && abs(vb - d_) > g.disp12MaxDiff;
                     if (c1 && c2) val = g.invalid16;
                 }
             }
+            out[x] = (int16_t)val;
         }
-        out[x] = (int16_t)val;
     }
 }
 
@@ -973,6 +1010,61 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
     srt(p3, p6); srt(p1, p4); srt(p2, p5); srt(p4, p7); srt(p4, p2); srt(p6, p4);
     srt(p4, p2);
     dst[(size_t)blockIdx.z * W * H + (size_t)y * W + x] = (int16_t)p4;
+}
+
+// Even widths: one thread owns a pixel pair (one 32-bit word) of MEDIAN_ROWS consecutive rows and works on
+// both pixels at once with packed 16-bit min/max.  Each input row's (left, centre, right) triple is
+// sorted once and shared by the three output rows that use it; the median of nine is then
+// med3(max of the lows, med3 of the middles, min of the highs).
+constexpr int MEDIAN_ROWS = 4;
+
+__device__ __forceinline__ uint32_t pk_med3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
+}
+
+__global__ void __launch_bounds__(256) k_median3_pairs(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst)
+{
+    const int WP = W >> 1;
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xp >= WP) return;
+    const int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * MEDIAN_ROWS;
+    if (y0 >= H) return;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (size_t)blockIdx.z * W * H);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst + (size_t)blockIdx.z * W * H);
+    uint32_t lo[MEDIAN_ROWS + 2], mi[MEDIAN_ROWS + 2], hi[MEDIAN_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < MEDIAN_ROWS + 2; r++) {
+        const int y = min(max(y0 + r - 1, 0), H - 1);
+        const uint32_t *p = s + (size_t)y * WP;
+        const uint32_t m = p[xp];
+        const uint32_t w0 = xp > 0 ? p[xp - 1] : (m << 16);      // replicated left border
+        const uint32_t w2 = xp + 1 < WP ? p[xp + 1] : (m >> 16); // replicated right border
+        uint32_t a = __builtin_amdgcn_alignbit(m, w0, 16);       // left neighbours of both pixels
+        uint32_t b = m;
+        uint32_t c = __builtin_amdgcn_alignbit(w2, m, 16);       // right neighbours
+        uint32_t t;
+        t = pk_min(a, b); b = pk_max(a, b); a = t;
+        t = pk_min(b, c); c = pk_max(b, c); b = t;
+        t = pk_min(a, b); b = pk_max(a, b); a = t;
+        lo[r] = a; mi[r] = b; hi[r] = c;
+    }
+#pragma unroll
+    for (int r = 0; r < MEDIAN_ROWS; r++) {
+        if (y0 + r >= H) break;
+        const uint32_t a = pk_max(pk_max(lo[r], lo[r + 1]), lo[r + 2]);
+        const uint32_t b = pk_med3(mi[r], mi[r + 1], mi[r + 2]);
+        const uint32_t c = pk_min(pk_min(hi[r], hi[r + 1]), hi[r + 2]);
+        d[(size_t)(y0 + r) * WP + xp] = pk_med3(a, b, c);
+    }
+}
+
+static void launch_median3(const int16_t *src, int W, int H, int B, int16_t *dst, hipStream_t s)
+{
+    if ((W & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0)
+        hipLaunchKernelGGL(k_median3_pairs, dim3(cdiv(W >> 1, 64), cdiv(H, 4 * MEDIAN_ROWS), B), dim3(64, 4), 0, s, src, W, H, dst);
+    else
+        hipLaunchKernelGGL(k_median3, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, src, W, H, dst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1445,7 +1537,7 @@ static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &
     const SgbmGeom &g = h->g;
     const size_t n = (size_t)g.W * g.H * B;
     const bool speckle = g.speckleWindowSize > 0;
-    hipLaunchKernelGGL(k_median3, dim3(cdiv(g.W, 256), g.H, B), dim3(256), 0, s, h->raw, g.W, g.H, d_disp);
+    launch_median3(h->raw, g.W, g.H, B, d_disp, s);
     stamp();
     if (speckle) {
         const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
@@ -1502,7 +1594,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
         return L3D_ERR_UNSUPPORTED;
     }
     stamp();
-    hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(256), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
+    hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(LR_THREADS), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
     stamp();
     {
         const int rc = sgbm_post(h, B, d_disp, s, stamp);

@@ -308,43 +308,42 @@ __global__ void __launch_bounds__(256) k_steger_rowbest(int nrows_total, int rh,
     }
 }
 
-// one block per image: exclusive scan of the cell counts in raster order, then gather
+// one block per image: exclusive scan of the cell counts in raster order; every thread then copies the few
+// points of its own cell (a cell holds the accepted pixels of 64 columns of one row: a handful at most on a
+// laser line) to where the scan says they go
 __global__ void __launch_bounds__(1024) k_steger_compact(int ncells, const float2 *__restrict__ cells, const int *__restrict__ cell_counts,
-                                                         int *__restrict__ cell_offsets, float2 *__restrict__ out, int capacity, int *__restrict__ counts)
+                                                         float2 *__restrict__ out, int capacity, int *__restrict__ counts)
 {
-    __shared__ int wsum[16];
-    __shared__ int carry;
+    __shared__ int wsum[2][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int *cc = cell_counts + (size_t)b * ncells;
-    int *co = cell_offsets + (size_t)b * ncells;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < ncells; base += 1024) {
+    const float2 *cs = cells + (size_t)b * ncells * TW;
+    float2 *o = out + (size_t)b * capacity;
+    int carry = 0; // points before this chunk: the same in every thread
+    for (int base = 0, it = 0; base < ncells; base += 1024, it ^= 1) {
         const int i = base + tid;
         const int v = i < ncells ? cc[i] : 0;
         int s = v; // inclusive scan inside the wave
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(s, o);
-            if (lane >= o) s += t;
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const int t = __shfl_up(s, o2);
+            if (lane >= o2) s += t;
         }
-        if (lane == 63) wsum[wv] = s;
-        __syncthreads();
-        int pre = carry;
-        for (int w = 0; w < wv; w++) pre += wsum[w];
-        if (i < ncells) co[i] = pre + s - v;
-        __syncthreads();
-        if (tid == 1023) carry = pre + s;
-        __syncthreads();
+        if (lane == 63) wsum[it][wv] = s;
+        __syncthreads(); // wsum is double-buffered: one barrier per chunk is enough
+        int pre = carry, total = carry;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int t = wsum[it][w];
+            if (w < wv) pre += t;
+            total += t;
+        }
+        carry = total;
+        const int off = pre + s - v;
+        const float2 *src = cs + (size_t)i * TW;
+        for (int k = 0; k < v && off + k < capacity; k++) o[off + k] = src[k];
     }
     if (tid == 0) counts[b] = carry;
-    // gather: one wave per cell
-    const float2 *cs = cells + (size_t)b * ncells * TW;
-    float2 *o = out + (size_t)b * capacity;
-    for (int c = wv; c < ncells; c += 16) {
-        const int n = cc[c], off = co[c];
-        if (lane < n && off + lane < capacity) o[off + lane] = cs[(size_t)c * TW + lane];
-    }
 }
 
 } // namespace l3d
@@ -359,7 +358,7 @@ struct l3d_steger {
     hipStream_t stream = nullptr;
     float *taps = nullptr;
     float2 *cells = nullptr;
-    int *cell_counts = nullptr, *cell_offsets = nullptr;
+    int *cell_counts = nullptr;
     // staging for the host entry point
     uint8_t *in = nullptr;
     float2 *out = nullptr;
@@ -372,7 +371,7 @@ extern "C" void l3d_steger_destroy(l3d_steger *h)
     if (!h) return;
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->taps, h->cells, h->cell_counts, h->cell_offsets, h->in, h->out, h->counts};
+    void *bufs[] = {h->taps, h->cells, h->cell_counts, h->in, h->out, h->counts};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -439,7 +438,6 @@ static int steger_create(double sigma, int brightness_threshold, int max_width, 
     alloc((void **)&h->taps, MAX_TAPS * sizeof(float));
     alloc((void **)&h->cells, B * h->max_cells * TW * sizeof(float2));
     alloc((void **)&h->cell_counts, B * h->max_cells * sizeof(int));
-    alloc((void **)&h->cell_offsets, B * h->max_cells * sizeof(int));
     alloc((void **)&h->in, B * (size_t)max_width * max_height * 3);
     alloc((void **)&h->out, B * (size_t)max_width * max_height * sizeof(float2));
     alloc((void **)&h->counts, B * sizeof(int));
@@ -486,7 +484,7 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
     if (variant == VAR_PER_ROW || variant == VAR_HYBRID)
         hipLaunchKernelGGL(k_steger_rowbest, dim3(cdiv(B * a.rh, 256)), dim3(256), 0, s, B * a.rh, a.rh, a.ntx, h->cells, h->cell_counts);
     const int ncells = a.rh * a.ntx;
-    hipLaunchKernelGGL(k_steger_compact, dim3(B), dim3(1024), 0, s, ncells, h->cells, h->cell_counts, h->cell_offsets, (float2 *)d_xy,
+    hipLaunchKernelGGL(k_steger_compact, dim3(B), dim3(1024), 0, s, ncells, h->cells, h->cell_counts, (float2 *)d_xy,
                        capacity, d_counts);
     L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;

@@ -218,6 +218,18 @@ def test_median_and_speckle_filter_on_handmade_maps(gpu, O, W, H, win, rng_):
     assert changed > 0  # the filter did erase something
 
 
+def test_median_on_small_and_ragged_maps(gpu, O):
+    """The 3x3 median alone (speckle filter off) on sizes around its pair / row-group boundaries."""
+    rng = np.random.default_rng(11)
+    kw = _ref_ctor(32, 5)
+    kw.update(speckleWindowSize=0)
+    for W, H in [(4, 1), (4, 7), (4, 4), (6, 17), (66, 33), (130, 16), (3, 1), (3, 5), (65, 18)]:
+        raw = rng.integers(-16, 1024, (3, H, W)).astype(np.int16)
+        got = _sgbm(**kw).postfilter(raw)
+        for k in range(3):
+            assert np.array_equal(got[k], O.median3_s16(raw[k])), (W, H, k)
+
+
 def test_sgbm_saturating_costs_match(gpu, O):
     # block 11 on maximum-contrast noise with large penalties drives min + P2 and L + P1 past 32767:
     # the 16-bit saturating arithmetic of the recurrence must agree
