@@ -619,8 +619,20 @@ struct SegLen {
 // Winner-take-all and uniqueness test for one column from the summed costs S, on all lanes of the
 // group.  Returns the group-uniform key (biased min S << 16 | argmin), or 0xFFFFFFFF when the
 // uniqueness test rejects the column.
+// `window` is a table in LDS (uniq_window_fill): entry r + 2, r = best - d0 clamped to -2 .. 2*NP+1, holds for each of
+// the lane's 2*NP disparities 32767 if it lies in best-1 .. best+1 and -32768 otherwise.
+template <int NP>
+__device__ __forceinline__ void uniq_window_fill(uint32_t *window, int tid, int nthreads)
+{
+    for (int i = tid; i < (2 * NP + 4) * NP; i += nthreads) {
+        const int r = i / NP - 2, p = i - (i / NP) * NP;
+        const uint32_t lo = abs(2 * p - r) <= 1 ? 0x7fffu : 0x8000u, hi = abs(2 * p + 1 - r) <= 1 ? 0x7fffu : 0x8000u;
+        window[i] = lo | (hi << 16);
+    }
+}
+
 template <int NP, int LPP>
-__device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0)
+__device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, const uint32_t *window)
 {
     uint32_t key = 0xffffffffu;
 #pragma unroll
@@ -637,18 +649,13 @@ __device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&
     const int lim = minS * 100, f = 100 - g.uniq;
     bool reject;
     if (f > 0) {
-        // some d outside best-1..best+1 has S[d]*f < lim  <=>  the minimum of S outside that window has.
-        // Bit e of `bits` marks entry e of this lane as inside the window; marked entries become 32767.
+        // some d outside best-1..best+1 has S[d]*f < lim  <=>  the minimum of S outside that window has:
+        // entries inside the window are raised to 32767 by a packed max with the table row of this lane
         const int r = min(max(best - d0, -2), 2 * NP + 1);
-        const uint32_t bits = (7u << (r + 2)) >> 3;
+        const Pack<NP> in_window = *reinterpret_cast<const Pack<NP> *>(window + (r + 2) * NP);
         uint32_t acc = 0x7fff7fffu;
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const uint32_t mlo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * p, 1);
-            const uint32_t mhi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * p + 1, 1);
-            const uint32_t m = (mlo & 0x0000ffffu) | (mhi & 0xffff0000u);
-            acc = pk_min(acc, (S[p] & ~m) | (m & 0x7fff7fffu));
-        }
+        for (int p = 0; p < NP; p++) acc = pk_min(acc, pk_max(S[p], in_window.v[p]));
         const int m2 = (int)(short)(group_min_splat<LPP>(acc) & 0xffffu);
         reject = __mul24(m2, f) < lim;
     } else {
@@ -740,7 +747,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // with one lane per (row, column) instead of once per column with one lane per row
     __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
     __shared__ uint32_t sK[RPW * SEG];
+    __shared__ __align__(16) uint32_t sWin[(2 * NP + 4) * NP];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
+    uniq_window_fill<NP>(sWin, tid, 64);
+    __syncthreads();
     const bool first = l == 0, last = l == LPP - 1;
     const int row0 = blockIdx.x * RPW;
     // groups past the last row redo the last row (their lanes are needed for the per-segment step) and store nothing
@@ -870,7 +880,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 Pack<NP> S;
 #pragma unroll
                 for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
-                const uint32_t key = wta_key<NP, LPP>(g, S.v, d0);
+                const uint32_t key = wta_key<NP, LPP>(g, S.v, d0, sWin);
                 *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
                 if (first) sK[grp * SEG + u] = key;
             }
