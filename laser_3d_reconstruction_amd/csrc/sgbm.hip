@@ -120,6 +120,16 @@ __device__ __forceinline__ uint32_t group_min_splat(uint32_t v)
     return (uint32_t)m;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Mapping the
+// hardware id through this permutation gives each XCD a contiguous range of logical ids, so blocks that read
+// the same rows or columns (neighbours in logical order, running at about the same time) share one L2.
+// Ids past the last full round of 8 map to themselves.
+__device__ __forceinline__ int xcd_contiguous(int id, int n)
+{
+    const int per = n >> 3;
+    return id < per * 8 ? (id & 7) * per + (id >> 3) : id;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
 // outstanding global load and store (vmcnt(0)), which would drain the row prefetch and expose
 // the latency of the volume stores at every row; the tiles exchanged here live in LDS.
@@ -402,7 +412,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     const bool first = l == 0, last = l == LPP - 1;
-    const int n = blockIdx.y, b = blockIdx.z;
+    // logical block: (column block, stripe, frame), column blocks of one stripe adjacent on one XCD
+    const int lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bx = lin % gridDim.x, n = (lin / gridDim.x) % gridDim.y, b = lin / (gridDim.x * gridDim.y);
     const int W = g.W, H = g.H, W1 = g.W1, SW2 = g.SW2, SH2 = g.SH2;
     const int start = max(min(n * g.stripe_sz - g.stripe_overlap, H), 0);
     const int end = min((n + 1) * g.stripe_sz, H);
@@ -417,7 +429,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     uint32_t *stage = smem;                         // [2][ 4 shifts [cstride >= 6 planes [nd]] | tileC records [2] ]
     uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
     uint32_t *ring = pixT + tileC * LPP * NP;       // [NR][256][NP], thread-private slots
-    const int xa = blockIdx.x * GPB;
+    const int xa = bx * GPB;
     const int xc_own = xa + grp;
     const bool active = xc_own < W1;
     const size_t plane = (size_t)W * H;
@@ -604,7 +616,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 
 // ---------------------------------------------------------------------------------------------
 // K3: left->right and right->left paths, sum of the three paths, WTA / uniqueness / sub-pixel.
-// One lane group per image row; a 64-thread block covers 64/LPP consecutive rows.
+// One lane group per image row; a wave covers 64/LPP consecutive rows.
 // The left->right costs are needed in right->left order.  Instead of spilling them to HBM the
 // first sweep stores only its state every SEG columns (checkpoints); the second sweep walks the
 // segments right to left, re-runs the left->right recurrence inside the segment from its
@@ -752,7 +764,9 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     uniq_window_fill<NP>(sWin, tid, 64);
     __syncthreads();
     const bool first = l == 0, last = l == LPP - 1;
-    const int row0 = blockIdx.x * RPW;
+    // Vertically adjacent row groups share a row of the volume: they run on one XCD.  (Putting them into one block
+    // of 2 or 4 waves shares that row through the L1 as well and moves 6% fewer bytes, but measured 7-10% slower.)
+    const int row0 = xcd_contiguous(blockIdx.x, gridDim.x) * RPW;
     // groups past the last row redo the last row (their lanes are needed for the per-segment step) and store nothing
     const bool row_ok = row0 + grp < nrows_total;
     const int grp_ld = min(grp, nrows_total - 1 - row0);

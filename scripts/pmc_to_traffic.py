@@ -6,6 +6,7 @@ at 64 bytes, i.e. reports half the bytes of a coalesced streaming read, so it is
 here on k_bgr2gray: 3 B/pixel read -> FETCH_SIZE*2*1024 == 3*W*H*B); WRITE_SIZE is exact.
 
 usage: pmc_to_traffic.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv> [tag] [batch]
+       pmc_to_traffic.py --print-only <fetch csv> <write csv>      (prints, leaves profiles/traffic.json alone)
 """
 import collections
 import csv
@@ -13,6 +14,7 @@ import json
 import os
 import sys
 
+print_only = sys.argv[1] == "--print-only"
 cfg, ffile, wfile = sys.argv[1:4]
 tag = sys.argv[4] if len(sys.argv) > 4 else "r1"
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 64
@@ -37,11 +39,12 @@ for k in sorted(set(f) | set(w)):
     out[k]["hbm_bytes"] = out[k]["fetch_bytes"] + out[k]["write_bytes"]
 sp = [k for k in out if k.startswith("k_speckle")]
 out["k_speckle_*"] = {"hbm_bytes": sum(out[k]["hbm_bytes"] for k in sp)}
-path = os.path.join(root, "profiles", "traffic.json")
-data = json.load(open(path)) if os.path.exists(path) else {}
-data[cfg] = {k: v["hbm_bytes"] for k, v in out.items()}
-data[cfg + "_batch"] = batch
-data[cfg + "_detail_" + tag] = out
-json.dump(data, open(path, "w"), indent=1)
+if not print_only:
+    path = os.path.join(root, "profiles", "traffic.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[cfg] = {k: v["hbm_bytes"] for k, v in out.items()}
+    data[cfg + "_batch"] = batch
+    data[cfg + "_detail_" + tag] = out
+    json.dump(data, open(path, "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
-    print(f"{k:22s} {v['hbm_bytes'] / 1e6:10.1f} MB / launch")
+    print(f"{k:22s} {v['hbm_bytes'] / 1e6:10.1f} MB / launch   fetch {v.get('fetch_bytes', 0) / 1e6:10.1f}  write {v.get('write_bytes', 0) / 1e6:10.1f}")
