@@ -46,6 +46,26 @@ struct DeviceGuard {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// Workgroups are handed to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Mapping the
+// hardware id through this permutation gives each XCD a contiguous range of logical ids, so blocks that read
+// the same rows or columns (neighbours in logical order, running at about the same time) share one L2.
+// Ids past the last full round of 8 map to themselves.
+__device__ __forceinline__ int xcd_contiguous(int id, int n)
+{
+    const int per = n >> 3;
+    return id < per * 8 ? (id & 7) * per + (id >> 3) : id;
+}
+// The logical block index of a 3-D grid (x fastest) under that mapping; use it in place of blockIdx.
+__device__ __forceinline__ dim3 xcd_block()
+{
+    const int gx = gridDim.x, gxy = gridDim.x * gridDim.y;
+    const int lin = xcd_contiguous(blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z, gxy * gridDim.z);
+    const int z = lin / gxy, r = lin - z * gxy, y = r / gx;
+    return dim3(r - y * gx, y, z);
+}
+#endif
+
 } // namespace l3d
 
 // Colour + brightness mask after the 3x3 close and open (stages shared by SimpleLaserExtractor and
@@ -53,6 +73,3 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int simple_clean_mask(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const int *lo, const int *hi, int thr, hipStream_t s,
                       const uint8_t **d_mask);
 
-namespace l3d {
-
-} // namespace l3d

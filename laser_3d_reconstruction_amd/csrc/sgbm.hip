@@ -120,16 +120,6 @@ __device__ __forceinline__ uint32_t group_min_splat(uint32_t v)
     return (uint32_t)m;
 }
 
-// Workgroups are handed to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Mapping the
-// hardware id through this permutation gives each XCD a contiguous range of logical ids, so blocks that read
-// the same rows or columns (neighbours in logical order, running at about the same time) share one L2.
-// Ids past the last full round of 8 map to themselves.
-__device__ __forceinline__ int xcd_contiguous(int id, int n)
-{
-    const int per = n >> 3;
-    return id < per * 8 ? (id & 7) * per + (id >> 3) : id;
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
 // outstanding global load and store (vmcnt(0)), which would drain the row prefetch and expose
 // the latency of the volume stores at every row; the tiles exchanged here live in LDS.
@@ -413,8 +403,8 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     const bool first = l == 0, last = l == LPP - 1;
     // logical block: (column block, stripe, frame), column blocks of one stripe adjacent on one XCD
-    const int lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
-    const int bx = lin % gridDim.x, n = (lin / gridDim.x) % gridDim.y, b = lin / (gridDim.x * gridDim.y);
+    const dim3 blk = xcd_block();
+    const int bx = blk.x, n = blk.y, b = blk.z;
     const int W = g.W, H = g.H, W1 = g.W1, SW2 = g.SW2, SH2 = g.SH2;
     const int start = max(min(n * g.stripe_sz - g.stripe_overlap, H), 0);
     const int end = min((n + 1) * g.stripe_sz, H);
@@ -1337,8 +1327,11 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
         }
         return lpp;
     };
-    g->LPPv = pick("L3D_SGBM_LPPV", g->D <= 96 ? 8 : 16);
-    g->LPPh = pick("L3D_SGBM_LPPH", (g->D <= 96 && g->tonly) ? 8 : 16);
+    // A lane holds an even number of disparities times NP: 16 lanes take multiples of 32 disparities, 8 lanes any
+    // multiple of 16 up to 128.
+    const bool only8 = g->D % 32 != 0;
+    g->LPPv = pick("L3D_SGBM_LPPV", (g->D <= 96 || only8) ? 8 : 16);
+    g->LPPh = pick("L3D_SGBM_LPPH", ((g->D <= 96 && g->tonly) || only8) ? 8 : 16);
     g->NPv = g->D / (2 * g->LPPv);
     g->NPh = g->D / (2 * g->LPPh);
     g->HR = g->H + 4;
@@ -1358,7 +1351,8 @@ static bool dispatch_variant(int NP, int LPP, F &&f)
         f(std::integral_constant<int, np>{}, std::integral_constant<int, lpp>{});             \
         return true;                                                                          \
     }
-    L3D_VARIANT(2, 8) L3D_VARIANT(4, 8) L3D_VARIANT(6, 8) L3D_VARIANT(8, 8)
+    L3D_VARIANT(1, 8) L3D_VARIANT(2, 8) L3D_VARIANT(3, 8) L3D_VARIANT(4, 8)
+    L3D_VARIANT(5, 8) L3D_VARIANT(6, 8) L3D_VARIANT(7, 8) L3D_VARIANT(8, 8)
     L3D_VARIANT(1, 16) L3D_VARIANT(2, 16) L3D_VARIANT(3, 16) L3D_VARIANT(4, 16)
     L3D_VARIANT(5, 16) L3D_VARIANT(6, 16) L3D_VARIANT(7, 16) L3D_VARIANT(8, 16)
 #undef L3D_VARIANT
@@ -1439,8 +1433,9 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         set_error("l3d_sgbm_create: only mode=2 (STEREO_SGBM_MODE_SGBM_3WAY) is built, got %d", p->mode);
         return L3D_ERR_UNSUPPORTED;
     }
-    if (p->numDisparities <= 0 || p->numDisparities % 32 != 0 || p->numDisparities > 256) {
-        set_error("l3d_sgbm_create: numDisparities must be a multiple of 32 in [32, 256], got %d", p->numDisparities);
+    if (p->numDisparities <= 0 || p->numDisparities % 16 != 0 || p->numDisparities > 256 ||
+        (p->numDisparities > 128 && p->numDisparities % 32 != 0)) {
+        set_error("l3d_sgbm_create: numDisparities must be a multiple of 16 up to 128 or a multiple of 32 up to 256, got %d", p->numDisparities);
         return L3D_ERR_UNSUPPORTED;
     }
     if (p->blockSize > 21) {

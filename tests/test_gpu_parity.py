@@ -66,6 +66,11 @@ def test_gray_bit_exact(gpu, O):
     (160, 48, 32, 1, 0, dict(P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=-1, preFilterCap=0)),  # defaults applied
     (240, 160, 32, 15, 0, {}),                                         # block 15: costs may pass 32767 -> both volumes are stored
     (240, 160, 64, 19, 0, {}),                                         # block 19: P2 = 34656 > 32767 as well
+    (200, 90, 16, 5, 0, {}),                                           # odd multiples of 16 disparities: 8 lanes per pixel,
+    (260, 100, 48, 7, 0, {}),                                          # an odd number of packed words per lane
+    (300, 80, 80, 5, -20, {}),
+    (330, 72, 112, 3, 0, {}),
+    (260, 100, 48, 15, 0, {}),                                         # ... and with both volumes stored
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
@@ -141,7 +146,7 @@ def test_sgbm_edge_cases(gpu, O):
     with pytest.raises(N.L3DError):
         _sgbm(**_ref_ctor(32, 11)).compute(np.zeros((12, 128), np.uint8), np.zeros((12, 128), np.uint8))
     with pytest.raises(N.L3DError):
-        _sgbm(**dict(_ref_ctor(48, 5))).compute(c, c)
+        _sgbm(**dict(_ref_ctor(144, 5))).compute(np.full((80, 400), 77, np.uint8), np.full((80, 400), 77, np.uint8))
     with pytest.raises(N.L3DError):
         _sgbm(**dict(_ref_ctor(64, 5), mode=0)).compute(c, c)
     with pytest.raises(TypeError):
