@@ -55,7 +55,7 @@ int l3d_device_count(int *n);
  * ------------------------------------------------------------------------- */
 typedef struct {
     int minDisparity;
-    int numDisparities;    /* multiple of 16 up to 128, multiple of 32 up to 256 */
+    int numDisparities;    /* multiple of 16 in [16, 256] */
     int blockSize;         /* odd, 1..21 */
     int P1, P2;
     int disp12MaxDiff;

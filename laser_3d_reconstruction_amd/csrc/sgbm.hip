@@ -50,6 +50,7 @@ struct SgbmGeom {
     // (D = 2 * NP * LPP), chosen separately for the vertical and the horizontal kernel: the volumes
     // between them are plain [column][disparity] arrays either way
     int LPPv, NPv, LPPh, NPh;
+    int Dp;   // disparities per volume column = 2 * NP * LPP: D, or D + 16 when D is an odd multiple of 16 above 128 (the tail is padding)
     // tonly: the aggregated-cost volume is not stored.  The vertical kernel writes the top->down path volume
     // only, with the per-column minimum beside it, into HR = H + 4 rows per frame: row y of stripe n sits at
     // y + n + 1 and the row before a stripe's first own row holds that stripe's path state entering it (zeros
@@ -198,9 +199,25 @@ __device__ __forceinline__ SgmPenalty make_penalty(const SgbmGeom &g)
 // in saturating int16 arithmetic.  `st` holds prev on entry and out on return; prevMin and the
 // returned min_d out carry the value in both halves.  `first` / `last` flag the group's end
 // lanes: inside a 16-lane DPP row a shift would otherwise pull in the neighbouring group's value.
-template <int NP, int LPP>
+//
+// PAD variants: the lane group holds 16 more disparities than the matcher has.  Those entries are pinned to
+// 32767 in every state, which is what the definition reads beyond the last disparity, so they never win a
+// minimum and the real entries see exactly the border they should.
+template <int NP, bool PAD>
+struct PadFlags {
+    bool on[NP];
+    // real_words = packed pairs of real disparities in a column
+    __device__ __forceinline__ void init(int lane_in_group, int real_words)
+    {
+#pragma unroll
+        for (int p = 0; p < NP; p++) on[p] = PAD && lane_in_group * NP + p >= real_words;
+    }
+    __device__ __forceinline__ uint32_t initial(int p) const { return (PAD && on[p]) ? 0x7fff7fffu : 0u; }
+};
+
+template <int NP, int LPP, bool PAD>
 __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[NP], uint32_t prevMin, const SgmPenalty &k, bool first,
-                                             bool last)
+                                             bool last, const PadFlags<NP, PAD> &pad)
 {
     const uint32_t BIG = 0x7fff7fffu;
     uint32_t mp2v = pk_adds(prevMin, k.P2a);
@@ -222,6 +239,7 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (
         const uint32_t a = pk_adds(pk_min(dm1, dp1), k.P1v);
         const uint32_t m = pk_min(a, pk_min(st[p], mp2v));
         out[p] = pk_adds(c[p], pk_subs(m, mp2v));
+        if (PAD) out[p] = pad.on[p] ? BIG : out[p];
         mn = pk_min(mn, out[p]);
     }
 #pragma unroll
@@ -392,7 +410,7 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // the copy that matches its offset.
 // Every global access is (block-uniform 64-bit base) + (per-lane 32-bit offset fixed for the whole
 // kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
-template <int NP, int LPP>
+template <int NP, int LPP, bool PAD>
 __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
@@ -412,9 +430,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     if (start >= end) return;
     const int NR = 2 * SH2 + 2;
     const int tileC = GPB + 2 * SW2;
-    const int nd = (tileC - 1 + g.D + 3) / 4 + 1;   // u32 words per staged right-image plane
+    const int nd = (tileC - 1 + g.Dp + 3) / 4 + 1;  // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
-    const int cstride = vertical_copy_stride(tileC, g.D);
+    const int cstride = vertical_copy_stride(tileC, g.Dp);
     const int stageW = 4 * cstride + 2 * tileC;     // = vertical_stage_words(tileC, D)
     uint32_t *stage = smem;                         // [2][ 4 shifts [cstride >= 6 planes [nd]] | tileC records [2] ]
     uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
@@ -454,9 +472,11 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         qword[ps] = (uint32_t)((o & 3) * cstride + (o >> 2));
     }
 
+    PadFlags<NP, PAD> pad;
+    pad.init(l, g.D / 2);
     uint32_t Cst[NP], Tst[NP], hs[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = 0; }
+    for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = pad.initial(p); }
     uint32_t topMin = 0;
     uint32_t sreg_lo[kStageLoadsMax], sreg_hi[kStageLoadsMax];
 
@@ -570,7 +590,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     for (int y = start; y < end; y++) {
         const bool box_now = (y + 1 < end) && (y + 1 + SH2 <= H - 1);
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
-        topMin = sgm_step<NP, LPP>(Cst, Tst, topMin, pen, first, last);
+        topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
         if (box_now) stage_put(y & 1);
         if (fetch_next) stage_fetch(y + 2 + SH2);
         if (y >= first_stored && active) {
@@ -735,7 +755,7 @@ struct ColIn<NP, true> {
     uint32_t m;
 };
 
-template <int NP, int LPP, bool TONLY>
+template <int NP, int LPP, bool TONLY, bool PAD>
 __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
                                                    const uint32_t *__restrict__ Tvol, const uint32_t *__restrict__ Mvol,
                                                    uint32_t *__restrict__ ckpt, uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
@@ -822,9 +842,11 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     Seg A, B;
 
     // ---- sweep 1: left -> right, keep the state at every segment start ----
+    PadFlags<NP, PAD> pad;
+    pad.init(l, g.D / 2);
     uint32_t st[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) st[p] = 0;
+    for (int p = 0; p < NP; p++) st[p] = pad.initial(p);
     uint32_t mn = 0;
     auto fetch1 = [&](Seg &s, int j) __attribute__((always_inline)) {
 #pragma unroll
@@ -837,7 +859,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)j * (uint32_t)col_bytes);
 #pragma unroll
         for (int u = 0; u < SEG; u++)
-            if (j * SEG + u < W1) mn = sgm_step<NP, LPP>(cost(s.c[u]), st, mn, pen, first, last);
+            if (j * SEG + u < W1) mn = sgm_step<NP, LPP, PAD>(cost(s.c[u]), st, mn, pen, first, last, pad);
     };
     fetch1(A, 0);
     for (int j = 0; j < nseg; j++) {
@@ -849,7 +871,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // ---- sweep 2: segments right -> left ----
     uint32_t rst[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) rst[p] = 0;
+    for (int p = 0; p < NP; p++) rst[p] = pad.initial(p);
     uint32_t rmn = 0;
     auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
         const int jc = max(j, 0);
@@ -869,7 +891,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP>(cost(s.c[u]), fst, fmn, pen, first, last);
+            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP, PAD>(cost(s.c[u]), fst, fmn, pen, first, last, pad);
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
@@ -880,7 +902,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 // (TONLY: cost() already ran on this column in the loop above and left C in place)
                 const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
                 const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
-                rmn = sgm_step<NP, LPP>(cu, rst, rmn, pen, first, last);
+                rmn = sgm_step<NP, LPP, PAD>(cu, rst, rmn, pen, first, last, pad);
                 Pack<NP> S;
 #pragma unroll
                 for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
@@ -1328,12 +1350,17 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
         return lpp;
     };
     // A lane holds an even number of disparities times NP: 16 lanes take multiples of 32 disparities, 8 lanes any
-    // multiple of 16 up to 128.
-    const bool only8 = g->D % 32 != 0;
-    g->LPPv = pick("L3D_SGBM_LPPV", (g->D <= 96 || only8) ? 8 : 16);
-    g->LPPh = pick("L3D_SGBM_LPPH", ((g->D <= 96 && g->tonly) || only8) ? 8 : 16);
-    g->NPv = g->D / (2 * g->LPPv);
-    g->NPh = g->D / (2 * g->LPPh);
+    // multiple of 16 up to 128.  An odd multiple of 16 above 128 runs on 16 lanes with 16 padding disparities.
+    const bool only8 = g->D % 32 != 0 && g->D <= 128;
+    g->Dp = (g->D % 32 != 0 && g->D > 128) ? g->D + 16 : g->D;
+    if (g->Dp != g->D) {
+        g->LPPv = g->LPPh = 16;
+    } else {
+        g->LPPv = pick("L3D_SGBM_LPPV", (g->D <= 96 || only8) ? 8 : 16);
+        g->LPPh = pick("L3D_SGBM_LPPH", ((g->D <= 96 && g->tonly) || only8) ? 8 : 16);
+    }
+    g->NPv = g->Dp / (2 * g->LPPv);
+    g->NPh = g->Dp / (2 * g->LPPh);
     g->HR = g->H + 4;
     return 0;
 }
@@ -1344,18 +1371,22 @@ using namespace l3d;
 
 // Calls f(integral_constant<NP>, integral_constant<LPP>) for the built kernel variant; false if there is none.
 template <typename F>
-static bool dispatch_variant(int NP, int LPP, F &&f)
+static bool dispatch_variant(int NP, int LPP, bool pad, F &&f)
 {
-#define L3D_VARIANT(np, lpp)                                                                  \
-    if (NP == np && LPP == lpp) {                                                             \
-        f(std::integral_constant<int, np>{}, std::integral_constant<int, lpp>{});             \
-        return true;                                                                          \
+#define L3D_VARIANT_PAD(np, lpp, pd)                                                                                     \
+    if (NP == np && LPP == lpp && pad == pd) {                                                                           \
+        f(std::integral_constant<int, np>{}, std::integral_constant<int, lpp>{}, std::integral_constant<bool, pd>{});    \
+        return true;                                                                                                     \
     }
+#define L3D_VARIANT(np, lpp) L3D_VARIANT_PAD(np, lpp, false)
     L3D_VARIANT(1, 8) L3D_VARIANT(2, 8) L3D_VARIANT(3, 8) L3D_VARIANT(4, 8)
     L3D_VARIANT(5, 8) L3D_VARIANT(6, 8) L3D_VARIANT(7, 8) L3D_VARIANT(8, 8)
     L3D_VARIANT(1, 16) L3D_VARIANT(2, 16) L3D_VARIANT(3, 16) L3D_VARIANT(4, 16)
     L3D_VARIANT(5, 16) L3D_VARIANT(6, 16) L3D_VARIANT(7, 16) L3D_VARIANT(8, 16)
+    // 144, 176, 208, 240 disparities
+    L3D_VARIANT_PAD(5, 16, true) L3D_VARIANT_PAD(6, 16, true) L3D_VARIANT_PAD(7, 16, true) L3D_VARIANT_PAD(8, 16, true)
 #undef L3D_VARIANT
+#undef L3D_VARIANT_PAD
     return false;
 }
 
@@ -1433,9 +1464,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         set_error("l3d_sgbm_create: only mode=2 (STEREO_SGBM_MODE_SGBM_3WAY) is built, got %d", p->mode);
         return L3D_ERR_UNSUPPORTED;
     }
-    if (p->numDisparities <= 0 || p->numDisparities % 16 != 0 || p->numDisparities > 256 ||
-        (p->numDisparities > 128 && p->numDisparities % 32 != 0)) {
-        set_error("l3d_sgbm_create: numDisparities must be a multiple of 16 up to 128 or a multiple of 32 up to 256, got %d", p->numDisparities);
+    if (p->numDisparities <= 0 || p->numDisparities % 16 != 0 || p->numDisparities > 256) {
+        set_error("l3d_sgbm_create: numDisparities must be a multiple of 16 in [16, 256], got %d", p->numDisparities);
         return L3D_ERR_UNSUPPORTED;
     }
     if (p->blockSize > 21) {
@@ -1460,8 +1490,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
                   height, p->blockSize, g.stripe_overlap, g.stripe_sz);
         return L3D_ERR_UNSUPPORTED;
     }
-    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.D) * sizeof(uint32_t);
-    if (vertical_stage_roles(256 / g.LPPv + 2 * g.SW2, g.D) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
+    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.Dp) * sizeof(uint32_t);
+    if (vertical_stage_roles(256 / g.LPPv + 2 * g.SW2, g.Dp) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
         delete h;
         set_error("l3d_sgbm_create: image %dx%d with %d disparities exceeds the input staging of the vertical kernel", width, height, g.D);
         return L3D_ERR_UNSUPPORTED;
@@ -1473,7 +1503,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     }
     DeviceGuard dg(device);
     const size_t B = (size_t)max_batch, px = (size_t)width * height;
-    const size_t vol = g.W1 > 0 ? B * height * (size_t)g.W1 * g.D * sizeof(int16_t) : 0;
+    const size_t vol = g.W1 > 0 ? B * height * (size_t)g.W1 * g.Dp * sizeof(int16_t) : 0;
     const size_t cols = g.W1 > 0 ? B * height * (size_t)g.W1 : 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     // every buffer is cleared once here: the first write to fresh device memory pays for mapping its
@@ -1489,13 +1519,13 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     alloc((void **)&h->rrev, B * px * 6 + 1024); // the row staging reads whole words past the last needed byte
     if (g.tonly) {
         // path-only layout: no aggregated-cost volume, H + 4 rows per frame, the per-column path minimum beside it
-        alloc((void **)&h->Tvol, g.W1 > 0 ? B * g.HR * (size_t)g.W1 * g.D * sizeof(int16_t) : 0);
+        alloc((void **)&h->Tvol, g.W1 > 0 ? B * g.HR * (size_t)g.W1 * g.Dp * sizeof(int16_t) : 0);
         alloc((void **)&h->Mvol, g.W1 > 0 ? B * g.HR * (size_t)g.W1 * sizeof(uint32_t) : 0);
     } else {
         alloc((void **)&h->Cvol, vol);
         alloc((void **)&h->Tvol, vol);
     }
-    alloc((void **)&h->Lvol, g.W1 > 0 ? B * height * (size_t)cdiv(g.W1, 4) * g.D * sizeof(int16_t) : 0);
+    alloc((void **)&h->Lvol, g.W1 > 0 ? B * height * (size_t)cdiv(g.W1, 4) * g.Dp * sizeof(int16_t) : 0);
     alloc((void **)&h->wta, cols * 4);
     alloc((void **)&h->dsub, cols * 2);
     alloc((void **)&h->raw, B * px * 2);
@@ -1516,8 +1546,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         // opt in to more than 64 KiB of dynamic LDS per block
         const size_t lds = h->lds_vertical;
         e = hipErrorInvalidValue;
-        dispatch_variant(g.NPv, g.LPPv, [&](auto np, auto lpp) {
-            e = hipFuncSetAttribute((const void *)k_cost_vertical<decltype(np)::value, decltype(lpp)::value>,
+        dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) {
+            e = hipFuncSetAttribute((const void *)k_cost_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         });
         if (e != hipSuccess) {
@@ -1530,23 +1560,23 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     return L3D_OK;
 }
 
-template <int NP, int LPP>
+template <int NP, int LPP, bool PAD>
 static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
-    hipLaunchKernelGGL((k_cost_vertical<NP, LPP>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
+    hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
 }
 
-template <int NP, int LPP>
+template <int NP, int LPP, bool PAD>
 static void launch_horizontal(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     const int nrows = B * g.H;
     if (g.tonly)
-        hipLaunchKernelGGL((k_horizontal<NP, LPP, true>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
+        hipLaunchKernelGGL((k_horizontal<NP, LPP, true, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
     else
-        hipLaunchKernelGGL((k_horizontal<NP, LPP, false>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
+        hipLaunchKernelGGL((k_horizontal<NP, LPP, false, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
 }
 
 // 3x3 median of h->raw into d_disp, then the speckle filter in place: the tail of StereoSGBM::compute
@@ -1605,9 +1635,9 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     hipLaunchKernelGGL(k_prefilter, dim3(cdiv(cdiv(g.W, 4) * g.H, 256), 1, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
-    const bool have_v = dispatch_variant(g.NPv, g.LPPv, [&](auto np, auto lpp) { launch_vertical<decltype(np)::value, decltype(lpp)::value>(h, B, s); });
+    const bool have_v = dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     stamp();
-    const bool have_h = dispatch_variant(g.NPh, g.LPPh, [&](auto np, auto lpp) { launch_horizontal<decltype(np)::value, decltype(lpp)::value>(h, B, s); });
+    const bool have_h = dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     if (!have_v || !have_h) {
         set_error("sgbm: no kernel variant for %d disparities", g.D);
         return L3D_ERR_UNSUPPORTED;
@@ -1670,20 +1700,22 @@ extern "C" int l3d_sgbm_postfilter(l3d_sgbm *h, const int16_t *raw, int batch, i
     return L3D_OK;
 }
 
-// Host-side rebuild of the stage volumes from the path-only layout (stage-level checks only): T rows are
-// gathered out of the padded volume; C = T - (what the recurrence added from the row above), in plain integers.
-static void tonly_unpack(const SgbmGeom &g, const std::vector<int16_t> &padded, int B, int stage, int16_t *dst)
+// Host-side rebuild of the stage volumes [B][H][W1][D] from the device layout (stage-level checks only).
+// Path-only layout: T rows are gathered out of the volume with its stripe padding rows; C = T - (what the
+// recurrence added from the row above), in plain integers.  Columns are Dp wide on the device, D here.
+static void stage_unpack(const SgbmGeom &g, const std::vector<int16_t> &dev, int B, int stage, int16_t *dst)
 {
-    const size_t col = (size_t)g.D, row = (size_t)g.W1 * col;
+    const size_t col = (size_t)g.Dp, row = (size_t)g.W1 * col, ocol = (size_t)g.D, orow = (size_t)g.W1 * ocol;
     const int P1 = std::min(g.P1, 32767);
     for (int b = 0; b < B; b++)
         for (int y = 0; y < g.H; y++) {
-            const size_t r = (size_t)b * g.HR + y + y / g.stripe_sz + 1;
-            const int16_t *T = padded.data() + r * row, *P = T - row;
-            int16_t *o = dst + ((size_t)b * g.H + y) * row;
-            if (stage == 1) { std::memcpy(o, T, row * sizeof(int16_t)); continue; }
+            const size_t r = g.tonly ? (size_t)b * g.HR + y + y / g.stripe_sz + 1 : (size_t)b * g.H + y;
+            const int16_t *T = dev.data() + r * row;
+            int16_t *o = dst + ((size_t)b * g.H + y) * orow;
             for (int x = 0; x < g.W1; x++) {
-                const int16_t *t = T + x * col, *p = P + x * col;
+                const int16_t *t = T + x * col;
+                if (!g.tonly || stage == 1) { std::memcpy(o + x * ocol, t, ocol * sizeof(int16_t)); continue; }
+                const int16_t *p = t - row; // the row above (a stripe's padding row above its first row)
                 int minp = 32767;
                 for (int d = 0; d < g.D; d++) minp = std::min(minp, (int)p[d]);
                 const int mp2 = std::min(minp + g.P2, 32767);
@@ -1691,7 +1723,7 @@ static void tonly_unpack(const SgbmGeom &g, const std::vector<int16_t> &padded, 
                     const int l = d > 0 ? p[d - 1] : 32767, r2 = d < g.D - 1 ? p[d + 1] : 32767;
                     const int a = std::min(std::min(l, r2) + P1, 32767);
                     const int m = std::min(a, std::min((int)p[d], mp2));
-                    o[x * col + d] = (int16_t)(t[d] - std::max(m - mp2, -32768));
+                    o[x * ocol + d] = (int16_t)(t[d] - std::max(m - mp2, -32768));
                 }
             }
         }
@@ -1716,11 +1748,11 @@ extern "C" int l3d_sgbm_fetch_stage(l3d_sgbm *h, int stage, void *host_dst, size
     DeviceGuard dg(h->device);
     L3D_HIP_CHECK(hipStreamSynchronize(h->stream));
     L3D_HIP_CHECK(hipDeviceSynchronize());
-    if (g.tonly && stage != 2) {
-        L3D_REQUIRE(bytes == avail, "l3d_sgbm_fetch_stage: the path-only layout returns whole stages (%zu bytes)", avail);
-        std::vector<int16_t> padded(B * g.HR * (size_t)g.W1 * g.D);
-        L3D_HIP_CHECK(hipMemcpy(padded.data(), h->Tvol, padded.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
-        tonly_unpack(g, padded, (int)B, stage, (int16_t *)host_dst);
+    if ((g.tonly || g.Dp != g.D) && stage != 2) {
+        L3D_REQUIRE(bytes == avail, "l3d_sgbm_fetch_stage: this volume layout returns whole stages (%zu bytes)", avail);
+        std::vector<int16_t> dev(B * (g.tonly ? g.HR : g.H) * (size_t)g.W1 * g.Dp);
+        L3D_HIP_CHECK(hipMemcpy(dev.data(), g.tonly ? h->Tvol : src, dev.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+        stage_unpack(g, dev, (int)B, stage, (int16_t *)host_dst);
         return L3D_OK;
     }
     L3D_HIP_CHECK(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));

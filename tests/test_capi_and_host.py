@@ -52,7 +52,7 @@ def test_argument_validation_needs_no_gpu():
     bad_mode = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 0)
     assert N.lib.l3d_sgbm_create(C.byref(bad_mode), 640, 360, 1, 0, C.byref(h)) == -2
     assert b"3WAY" in N.lib.l3d_last_error()
-    bad_d = N.SgbmParams(0, 144, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
+    bad_d = N.SgbmParams(0, 24, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
     assert N.lib.l3d_sgbm_create(C.byref(bad_d), 640, 360, 1, 0, C.byref(h)) == -2
     out = (C.c_int * 8)()
     ok = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 2)

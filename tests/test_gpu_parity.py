@@ -71,6 +71,12 @@ def test_gray_bit_exact(gpu, O):
     (300, 80, 80, 5, -20, {}),
     (330, 72, 112, 3, 0, {}),
     (260, 100, 48, 15, 0, {}),                                         # ... and with both volumes stored
+    (300, 64, 144, 5, 0, {}),                                          # odd multiples of 16 above 128: 16 lanes per pixel with
+    (330, 56, 176, 7, 0, {}),                                          # 16 padding disparities pinned to the border value
+    (360, 48, 208, 3, -8, {}),
+    (400, 48, 240, 5, 0, dict(uniquenessRatio=0)),
+    (300, 64, 144, 15, 0, {}),                                         # ... and with both volumes stored
+    (420, 40, 256, 5, 0, {}),                                          # the largest range
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
@@ -146,7 +152,7 @@ def test_sgbm_edge_cases(gpu, O):
     with pytest.raises(N.L3DError):
         _sgbm(**_ref_ctor(32, 11)).compute(np.zeros((12, 128), np.uint8), np.zeros((12, 128), np.uint8))
     with pytest.raises(N.L3DError):
-        _sgbm(**dict(_ref_ctor(144, 5))).compute(np.full((80, 400), 77, np.uint8), np.full((80, 400), 77, np.uint8))
+        _sgbm(**dict(_ref_ctor(24, 5))).compute(c, c)
     with pytest.raises(N.L3DError):
         _sgbm(**dict(_ref_ctor(64, 5), mode=0)).compute(c, c)
     with pytest.raises(TypeError):
@@ -241,14 +247,16 @@ def test_sgbm_saturating_costs_match(gpu, O):
     rng = np.random.default_rng(5)
     a = (rng.integers(0, 2, (96, 300)) * 255).astype(np.uint8)
     b = (rng.integers(0, 2, (96, 300)) * 255).astype(np.uint8)
-    kw = _ref_ctor(64, 11)
-    kw.update(P1=25000, P2=30000)
-    m = _sgbm(**kw)
-    got = m.compute(a, b)
-    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), a, b)
-    assert int(dbg.C.max()) + 30000 > 32767
-    assert np.array_equal(m.fetch_stage(1, 1, 300, 96)[0], dbg.T)
-    assert np.array_equal(got, dbg.disp)
+    # 64: plain; 48: odd word count per lane; 144: padded disparities, whose pinned entries sit at the saturation value
+    for D, p2 in ((64, 30000), (48, 30000), (144, 30000), (144, 40000)):
+        kw = _ref_ctor(D, 11)
+        kw.update(P1=25000, P2=p2)
+        m = _sgbm(**kw)
+        got = m.compute(a, b)
+        dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), a, b)
+        assert int(dbg.C.max()) + 30000 > 32767
+        assert np.array_equal(m.fetch_stage(1, 1, 300, 96)[0], dbg.T), D
+        assert np.array_equal(got, dbg.disp), D
 
 
 def test_wls_pipeline_bit_exact(gpu, O):
