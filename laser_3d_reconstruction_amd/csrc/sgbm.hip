@@ -1351,8 +1351,11 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     };
     // A lane holds an even number of disparities times NP: 16 lanes take multiples of 32 disparities, 8 lanes any
     // multiple of 16 up to 128.  An odd multiple of 16 above 128 runs on 16 lanes with 16 padding disparities.
-    const bool only8 = g->D % 32 != 0 && g->D <= 128;
-    g->Dp = (g->D % 32 != 0 && g->D > 128) ? g->D + 16 : g->D;
+    // So does 112 with blockSize 19 or 21, whose ring of box rows does not fit the LDS with 8 lanes per pixel.
+    const bool odd16 = g->D % 32 != 0;
+    const bool pad = odd16 && (g->D > 128 || vertical_lds_words(8, g->D / 16, g->SW2, g->SH2, g->D) * sizeof(uint32_t) > 160 * 1024);
+    const bool only8 = odd16 && !pad;
+    g->Dp = pad ? g->D + 16 : g->D;
     if (g->Dp != g->D) {
         g->LPPv = g->LPPh = 16;
     } else {
@@ -1383,8 +1386,8 @@ static bool dispatch_variant(int NP, int LPP, bool pad, F &&f)
     L3D_VARIANT(5, 8) L3D_VARIANT(6, 8) L3D_VARIANT(7, 8) L3D_VARIANT(8, 8)
     L3D_VARIANT(1, 16) L3D_VARIANT(2, 16) L3D_VARIANT(3, 16) L3D_VARIANT(4, 16)
     L3D_VARIANT(5, 16) L3D_VARIANT(6, 16) L3D_VARIANT(7, 16) L3D_VARIANT(8, 16)
-    // 144, 176, 208, 240 disparities
-    L3D_VARIANT_PAD(5, 16, true) L3D_VARIANT_PAD(6, 16, true) L3D_VARIANT_PAD(7, 16, true) L3D_VARIANT_PAD(8, 16, true)
+    // 144, 176, 208, 240 disparities (and 112 with the largest blocks)
+    L3D_VARIANT_PAD(4, 16, true) L3D_VARIANT_PAD(5, 16, true) L3D_VARIANT_PAD(6, 16, true) L3D_VARIANT_PAD(7, 16, true) L3D_VARIANT_PAD(8, 16, true)
 #undef L3D_VARIANT
 #undef L3D_VARIANT_PAD
     return false;

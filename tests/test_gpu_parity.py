@@ -77,6 +77,8 @@ def test_gray_bit_exact(gpu, O):
     (400, 48, 240, 5, 0, dict(uniquenessRatio=0)),
     (300, 64, 144, 15, 0, {}),                                         # ... and with both volumes stored
     (420, 40, 256, 5, 0, {}),                                          # the largest range
+    (300, 64, 112, 19, 0, {}),                                         # 112 with a block whose ring needs the padded 16-lane form
+    (280, 64, 96, 21, 0, {}),                                          # the largest block
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
