@@ -769,6 +769,11 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // with one lane per (row, column) instead of once per column with one lane per row
     __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
     __shared__ uint32_t sK[RPW * SEG];
+    // results of OSEG segments per row, so that they leave as 64-byte (keys) and 32-byte (disparities) runs:
+    // 16- and 8-byte stores scattered over rows reached HBM as partial lines (+40 % write traffic)
+    constexpr int OSEG = 16 / SEG > 0 ? 16 / SEG : 1, OCOL = OSEG * SEG;
+    __shared__ uint32_t oK[RPW * OCOL];
+    __shared__ int16_t oD[RPW * OCOL];
     __shared__ __align__(16) uint32_t sWin[(2 * NP + 4) * NP];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     uniq_window_fill<NP>(sWin, tid, 64);
@@ -830,8 +835,9 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // role of this lane in the per-segment step: column u of row e_grp
     const int e_u = tid % SEG, e_grp = tid / SEG;
     const bool e_on = tid < RPW * SEG && row0 + e_grp < nrows_total;
-    uint32_t *wrow = wta + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
-    int16_t *drow = dsub + ((size_t)row0 + (e_on ? e_grp : 0)) * W1;
+    uint32_t *wblk = wta + (size_t)row0 * W1;
+    int16_t *dblk = dsub + (size_t)row0 * W1;
+    const int rows_here = min(RPW, nrows_total - row0);
 
     // segment being consumed (A) and segment in flight (B)
     struct Seg {
@@ -923,8 +929,21 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                     const int16_t *rec = sS + 8 + tid * REC + best;
                     dval = subpixel_disp(g, best, rec[-1], (int)(key >> 16) - 32768, rec[1]);
                 }
-                wrow[xc] = key;
-                drow[xc] = (int16_t)dval;
+                const int slot = e_grp * OCOL + (j % OSEG) * SEG + e_u;
+                oK[slot] = key;
+                oD[slot] = (int16_t)dval;
+            }
+        }
+        if (j % OSEG == 0) {
+            // the columns j*SEG .. j*SEG+OCOL-1 of every row are complete
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = tid; i < RPW * OCOL; i += 64) {
+                const int r = i / OCOL, c = i - r * OCOL, x = j * SEG + c;
+                if (r < rows_here && x < W1) {
+                    wblk[(size_t)r * W1 + x] = oK[i];
+                    dblk[(size_t)r * W1 + x] = oD[i];
+                }
             }
         }
         asm volatile("" ::: "memory");
