@@ -221,7 +221,12 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (
 {
     const uint32_t BIG = 0x7fff7fffu;
     uint32_t mp2v = pk_adds(prevMin, k.P2a);
-    if (k.P2b) mp2v = pk_adds(pk_adds(mp2v, k.P2b), k.P2c);
+    if (k.P2b) {
+        // kernel-uniform and rare (P2 > 32767): the empty statement keeps this a branch instead of two
+        // additions and a select on every step
+        asm volatile("" ::: "memory");
+        mp2v = pk_adds(pk_adds(mp2v, k.P2b), k.P2c);
+    }
     uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
     uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, st[0]);      // lane+1's bottom pair
     if (LPP < 16) {
@@ -357,21 +362,6 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
 // ---------------------------------------------------------------------------------------------
 // K2: pixel cost -> box aggregation -> top->down path, one block per (256/LPP columns, stripe, frame)
 // ---------------------------------------------------------------------------------------------
-// 2*NP consecutive bytes (one per disparity) from a byte-aligned address into whole registers
-template <int NP>
-__device__ __forceinline__ void load_bytes(const uint8_t *p, uint32_t (&dst)[(NP + 1) / 2])
-{
-    if (NP & 1) dst[NP / 2] = 0;
-    __builtin_memcpy(dst, p, 2 * NP);
-}
-// bytes 2p and 2p+1 of such a register array, widened to a packed pair of u16: one v_perm_b32
-template <int NP>
-__device__ __forceinline__ uint32_t byte_pair(const uint32_t (&w)[(NP + 1) / 2], int p)
-{
-    const uint32_t x = w[p >> 1];
-    return (p & 1) ? __builtin_amdgcn_perm(x, x, 0x0c030c02u) : __builtin_amdgcn_perm(x, x, 0x0c010c00u);
-}
-
 // Birchfield-Tomasi cost of one channel for a packed pair of disparities
 __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1)
 {
@@ -380,17 +370,20 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
     return pku_min(c0, c1);
 }
 
-// LDS footprint of the vertical kernel in u32 words: two input stages, the pixel-cost tile, the ring
-// one stage = 4 byte-shifted copies of the 6 right-image plane runs + the left records; `roles` = 8-byte fetches per row
+// LDS footprint of the vertical kernel in u32 words: two input stages, the pixel-cost tile, the ring.
+// One stage = the 6 right-image plane runs widened to 16 bits per value, twice (starting at byte 0 and at byte 1),
+// + 6 words per tile column for the left pixel; `roles` = 8-byte fetches per row
 __host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + tileC; }
-// words between two shifted copies: at least the 6 plane runs, and 16 modulo 64 so that the lane groups of
-// a wave, which read from all four copies at once, spread over all 64 LDS banks
+// words between the two copies: at least the 6 widened plane runs, and 2 modulo 4.  A lane reads NP consecutive
+// words and its neighbours in the group the next ones, so a group covers every fourth bank (NP = 4); the groups of
+// adjacent columns start one value apart, i.e. in alternating copies and every second time one word lower:
+// with the second copy displaced by 2 banks modulo 4, four adjacent groups start on four different banks modulo 4.
 __host__ __device__ inline int vertical_copy_stride(int tileC, int D)
 {
-    const int w = 6 * ((tileC - 1 + D + 3) / 4 + 1);
-    return (w - 16 + 63) / 64 * 64 + 16;
+    const int w = 12 * ((tileC - 1 + D + 3) / 4 + 1);
+    return (w + 3) / 4 * 4 + 2;
 }
-__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 4 * vertical_copy_stride(tileC, D) + 2 * tileC; }
+__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 2 * vertical_copy_stride(tileC, D) + 6 * tileC; }
 __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D)
 {
     const int tileC = 256 / LPP + 2 * SW2;
@@ -406,8 +399,10 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // columns overlap in it).  Those ~1 KB are fetched once per row by the first few lanes of the block,
 // one row ahead, instead of 2*NP bytes per plane per lane from the vector cache.  A lane's 2*NP
 // bytes start at an arbitrary byte of the run and misaligned LDS reads stall the LDS pipeline, so
-// the run is staged four times, shifted by 0..3 bytes: every lane reads whole aligned words from
-// the copy that matches its offset.
+// the run is staged twice, starting at byte 0 and at byte 1, and already widened to one 16-bit value
+// per byte (the form the packed cost arithmetic needs): every lane reads whole aligned words from
+// the copy that matches the parity of its offset and uses them as they are.  The six values of the
+// left pixel are staged as ready-made 16-bit splats for the same reason.
 // Every global access is (block-uniform 64-bit base) + (per-lane 32-bit offset fixed for the whole
 // kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
 template <int NP, int LPP, bool PAD>
@@ -433,8 +428,8 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int nd = (tileC - 1 + g.Dp + 3) / 4 + 1;  // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
     const int cstride = vertical_copy_stride(tileC, g.Dp);
-    const int stageW = 4 * cstride + 2 * tileC;     // = vertical_stage_words(tileC, D)
-    uint32_t *stage = smem;                         // [2][ 4 shifts [cstride >= 6 planes [nd]] | tileC records [2] ]
+    const int stageW = 2 * cstride + 6 * tileC;     // = vertical_stage_words(tileC, D)
+    uint32_t *stage = smem;                         // [2][ 2 copies [cstride >= 6 planes [2 * nd]] | tileC left pixels [6] ]
     uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
     uint32_t *ring = pixT + tileC * LPP * NP;       // [NR][256][NP], thread-private slots
     const int xa = bx * GPB;
@@ -461,15 +456,15 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         s_left[e] = i >= 6 * nd;
         const int w = i - 6 * nd;                    // left: tile column
         const int j = i / nd, idx = i - j * nd;      // right: plane, word
-        s_lidx[e] = s_left[e] ? (uint32_t)(4 * cstride + 2 * w) : (uint32_t)i; // copy s lies s * cstride words further
+        s_lidx[e] = s_left[e] ? (uint32_t)(2 * cstride + 6 * w) : (uint32_t)(2 * i); // the second copy lies cstride words further
         s_goff[e] = s_left[e] ? (uint32_t)tile_x(w) * (uint32_t)sizeof(uint2) : (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
     }
     // byte offset inside a staged plane of the first disparity this lane needs, per tile column
-    uint32_t qword[NPS]; // as a word index into the stage: copy (offset & 3), word (offset >> 2)
+    uint32_t qword[NPS]; // as a word index into the stage: copy (offset & 1), word (offset >> 1)
 #pragma unroll
     for (int ps = 0; ps < NPS; ps++) {
         const int o = x_hi - tile_x(min(grp + GPB * ps, tileC - 1)) + l * 2 * NP;
-        qword[ps] = (uint32_t)((o & 3) * cstride + (o >> 2));
+        qword[ps] = (uint32_t)((o & 1) * cstride + (o >> 1));
     }
 
     PadFlags<NP, PAD> pad;
@@ -498,13 +493,16 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         for (int e = 0; e < kStageLoadsMax; e++) {
             if (e * 256 < nroles && s_on[e]) {
                 const uint32_t lo = sreg_lo[e], hi = sreg_hi[e];
-                st[s_lidx[e]] = lo;
+                uint32_t *o = st + s_lidx[e];
                 if (s_left[e]) {
-                    st[s_lidx[e] + 1] = hi;
+                    // value, half-pixel minimum and maximum of the gradient image, then of the intensity image
+                    o[0] = __builtin_amdgcn_perm(lo, lo, 0x0c000c00u); o[1] = __builtin_amdgcn_perm(lo, lo, 0x0c010c01u);
+                    o[2] = __builtin_amdgcn_perm(lo, lo, 0x0c020c02u); o[3] = __builtin_amdgcn_perm(hi, hi, 0x0c000c00u);
+                    o[4] = __builtin_amdgcn_perm(hi, hi, 0x0c010c01u); o[5] = __builtin_amdgcn_perm(hi, hi, 0x0c020c02u);
                 } else {
-                    st[s_lidx[e] + cstride] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-                    st[s_lidx[e] + 2 * cstride] = __builtin_amdgcn_alignbyte(hi, lo, 2);
-                    st[s_lidx[e] + 3 * cstride] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+                    // bytes 0..3 of the word as two pairs, and the same from byte 1 on
+                    o[0] = __builtin_amdgcn_perm(hi, lo, 0x0c010c00u); o[1] = __builtin_amdgcn_perm(hi, lo, 0x0c030c02u);
+                    o[cstride] = __builtin_amdgcn_perm(hi, lo, 0x0c020c01u); o[cstride + 1] = __builtin_amdgcn_perm(hi, lo, 0x0c040c03u);
                 }
             }
         }
@@ -519,24 +517,21 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         for (int ps = 0; ps < NPS; ps++) {
             const int c = grp + GPB * ps;
             if (c < tileC) {
-                const uint2 lr = *reinterpret_cast<const uint2 *>(st + 4 * cstride + 2 * c);
-                const uint32_t u = pk_splat(lr.x & 0xff), u0 = pk_splat((lr.x >> 8) & 0xff), u1 = pk_splat((lr.x >> 16) & 0xff);
-                const uint32_t t = pk_splat(lr.y & 0xff), t0 = pk_splat((lr.y >> 8) & 0xff), t1 = pk_splat((lr.y >> 16) & 0xff);
-                uint32_t q[6][(NP + 1) / 2];
+                const uint32_t *lp = st + 2 * cstride + 6 * c;
+                const uint32_t u = lp[0], u0 = lp[1], u1 = lp[2], t = lp[3], t0 = lp[4], t1 = lp[5];
+                uint32_t q[6][NP];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
 #pragma unroll
-                    for (int w = 0; w < (NP + 1) / 2; w++) q[j][w] = st[j * nd + qword[ps] + w];
+                    for (int w = 0; w < NP; w++) q[j][w] = st[j * 2 * nd + qword[ps] + w];
                 }
                 Pack<NP> px;
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
-                    uint32_t v[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) v[j] = byte_pair<NP>(q[j], p);
-                    const uint32_t cg = bt_pair(u, u0, u1, v[0], v[1], v[2]);
-                    const uint32_t ci = bt_pair(t, t0, t1, v[3], v[4], v[5]);
-                    px.v[p] = cg + ((ci >> 2) & 0x3fff3fffu);
+                    const uint32_t cg = bt_pair(u, u0, u1, q[0][p], q[1][p], q[2][p]);
+                    const uint32_t ci = bt_pair(t, t0, t1, q[3][p], q[4][p], q[5][p]);
+                    const v2u two = {2, 2};
+                    px.v[p] = cg + as_u32u(as_v2u(ci) >> two);
                 }
                 *reinterpret_cast<Pack<NP> *>(pixT + (c * LPP + l) * NP) = px;
             }
@@ -593,7 +588,11 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
         if (box_now) stage_put(y & 1);
         if (fetch_next) stage_fetch(y + 2 + SH2);
+#ifdef L3D_DEV_NOSTORE
+        if (y == end - 1 && active) {
+#else
         if (y >= first_stored && active) {
+#endif
             Pack<NP> pc, pt;
 #pragma unroll
             for (int p = 0; p < NP; p++) { pc.v[p] = Cst[p]; pt.v[p] = Tst[p]; }
@@ -635,7 +634,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 // ---------------------------------------------------------------------------------------------
 template <int NP, bool TONLY>
 struct SegLen {
-    static constexpr int value = (NP <= 2 && !TONLY) ? 8 : 4; // TONLY prefetches three operands per column
+    static constexpr int value = ((NP <= 2 && !TONLY) || (NP == 4 && TONLY)) ? 8 : 4; // TONLY prefetches three operands per column
 };
 
 // Winner-take-all and uniqueness test for one column from the summed costs S, on all lanes of the
@@ -814,8 +813,12 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         ColIn<NP, TONLY> r;
         if constexpr (TONLY) {
             r.t = buf_load<NP>(Tr, voff, xc * (uint32_t)col_bytes);
+#ifdef L3D_DEV_NOP
+            r.p = r.t; r.m = 0;
+#else
             r.p = buf_load<NP>(Tr, poff, xc * (uint32_t)col_bytes);
             r.m = __builtin_amdgcn_raw_buffer_load_b32(Mr, moff, xc * (uint32_t)sizeof(uint32_t), 0);
+#endif
         } else
             r.c = buf_load<NP>(Cr, voff, xc * (uint32_t)col_bytes);
         return r;
@@ -854,26 +857,38 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = pad.initial(p);
     uint32_t mn = 0;
-    auto fetch1 = [&](Seg &s, int j) __attribute__((always_inline)) {
+    // The columns pass through a ring of 2 * SEG register slots: the slot of a column is refilled, right after
+    // its use, with the column 2 * SEG further on, so every load has the time of 2 * SEG steps to arrive.  (This
+    // sweep has a third of the arithmetic of the second one per column: with whole segments fetched one segment
+    // ahead it waited for memory.)
+    {
+        constexpr int RING = 2 * SEG;
+        ColIn<NP, TONLY> ring[RING];
 #pragma unroll
-        for (int u = 0; u < SEG; u++) s.c[u] = fetch(j * SEG + u);
-    };
-    auto run1 = [&](Seg &s, int j) __attribute__((always_inline)) {
-        Pack<NP> o;
+        for (int u = 0; u < RING; u++) ring[u] = fetch(u);
+        for (int x0 = 0; x0 < W1; x0 += RING) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) o.v[p] = st[p];
-        if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)j * (uint32_t)col_bytes);
+            for (int u = 0; u < RING; u++) {
+                const int x = x0 + u;
+                if (x < W1) {
+                    if (u % SEG == 0) {
+                        Pack<NP> o;
 #pragma unroll
-        for (int u = 0; u < SEG; u++)
-            if (j * SEG + u < W1) mn = sgm_step<NP, LPP, PAD>(cost(s.c[u]), st, mn, pen, first, last, pad);
-    };
-    fetch1(A, 0);
-    for (int j = 0; j < nseg; j++) {
-        fetch1(B, j + 1);
-        run1(A, j);
-        A = B;
+                        for (int p = 0; p < NP; p++) o.v[p] = st[p];
+#ifndef L3D_DEV_NOCKPT
+                        if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)(x / SEG) * (uint32_t)col_bytes);
+#endif
+                    }
+                    mn = sgm_step<NP, LPP, PAD>(cost(ring[u]), st, mn, pen, first, last, pad);
+                }
+                ring[u] = fetch(x + RING);
+            }
+        }
     }
 
+#ifdef L3D_DEV_SWEEP1_ONLY
+    if (g.W > 0) return;
+#endif
     // ---- sweep 2: segments right -> left ----
     uint32_t rst[NP];
 #pragma unroll
@@ -1365,6 +1380,7 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
         if (const char *ov = std::getenv(name)) {
             const int v = std::atoi(ov);
             if ((v == 8 || v == 16) && g->D % (2 * v) == 0 && g->D / (2 * v) <= 8) lpp = v;
+            if (v == 4 && g->D == 64 && g->tonly && name[12] == 'H') lpp = v;
         }
         return lpp;
     };
@@ -1659,7 +1675,12 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     const bool have_v = dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     stamp();
-    const bool have_h = dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
+    bool have_h4 = false;
+    if (g.LPPh == 4 && g.NPh == 8 && g.Dp == g.D) {
+        launch_horizontal<8, 4, false>(h, B, s);
+        have_h4 = true;
+    }
+    const bool have_h = have_h4 || dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     if (!have_v || !have_h) {
         set_error("sgbm: no kernel variant for %d disparities", g.D);
         return L3D_ERR_UNSUPPORTED;
