@@ -588,11 +588,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
         if (box_now) stage_put(y & 1);
         if (fetch_next) stage_fetch(y + 2 + SH2);
-#ifdef L3D_DEV_NOSTORE
-        if (y == end - 1 && active) {
-#else
         if (y >= first_stored && active) {
-#endif
             Pack<NP> pc, pt;
 #pragma unroll
             for (int p = 0; p < NP; p++) { pc.v[p] = Cst[p]; pt.v[p] = Tst[p]; }
@@ -813,12 +809,8 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         ColIn<NP, TONLY> r;
         if constexpr (TONLY) {
             r.t = buf_load<NP>(Tr, voff, xc * (uint32_t)col_bytes);
-#ifdef L3D_DEV_NOP
-            r.p = r.t; r.m = 0;
-#else
             r.p = buf_load<NP>(Tr, poff, xc * (uint32_t)col_bytes);
             r.m = __builtin_amdgcn_raw_buffer_load_b32(Mr, moff, xc * (uint32_t)sizeof(uint32_t), 0);
-#endif
         } else
             r.c = buf_load<NP>(Cr, voff, xc * (uint32_t)col_bytes);
         return r;
@@ -875,9 +867,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                         Pack<NP> o;
 #pragma unroll
                         for (int p = 0; p < NP; p++) o.v[p] = st[p];
-#ifndef L3D_DEV_NOCKPT
                         if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)(x / SEG) * (uint32_t)col_bytes);
-#endif
                     }
                     mn = sgm_step<NP, LPP, PAD>(cost(ring[u]), st, mn, pen, first, last, pad);
                 }
@@ -886,9 +876,6 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         }
     }
 
-#ifdef L3D_DEV_SWEEP1_ONLY
-    if (g.W > 0) return;
-#endif
     // ---- sweep 2: segments right -> left ----
     uint32_t rst[NP];
 #pragma unroll
@@ -1374,13 +1361,13 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; both kernels gain from
     // that up to 96 disparities (measured: slower again at 128) -- the horizontal one only in the path-only scheme, where it is bound by vector
     // instructions; with both volumes it is bound by memory stalls and needs the wave count of 16 lanes per row.
+    // (4 lanes per row, 16 rows per wave, measured the same as 8 in the horizontal kernel at 64 disparities: not built.)
     // L3D_SGBM_LPPV / L3D_SGBM_LPPH = 8|16 override the choice (experiments).
     auto pick = [&](const char *name, int dflt) {
         int lpp = dflt;
         if (const char *ov = std::getenv(name)) {
             const int v = std::atoi(ov);
             if ((v == 8 || v == 16) && g->D % (2 * v) == 0 && g->D / (2 * v) <= 8) lpp = v;
-            if (v == 4 && g->D == 64 && g->tonly && name[12] == 'H') lpp = v;
         }
         return lpp;
     };
@@ -1675,12 +1662,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
     stamp();
     const bool have_v = dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     stamp();
-    bool have_h4 = false;
-    if (g.LPPh == 4 && g.NPh == 8 && g.Dp == g.D) {
-        launch_horizontal<8, 4, false>(h, B, s);
-        have_h4 = true;
-    }
-    const bool have_h = have_h4 || dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
+    const bool have_h = dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     if (!have_v || !have_h) {
         set_error("sgbm: no kernel variant for %d disparities", g.D);
         return L3D_ERR_UNSUPPORTED;
