@@ -86,6 +86,12 @@ __device__ __forceinline__ uint32_t dpp_row(uint32_t fill, uint32_t src)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)src, CTRL, 0xf, 0xf, false);
 }
+// The same move when the value of lanes without a source does not matter (they read 0): no destination to initialise
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row_any(uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xf, 0xf, true);
+}
 #define DPP_ROW_SHL1 0x101        // lane i <- lane i+1
 #define DPP_ROW_SHR1 0x111        // lane i <- lane i-1
 #define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]: lane i <- lane i^1
@@ -227,8 +233,10 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (
         asm volatile("" ::: "memory");
         mp2v = pk_adds(pk_adds(mp2v, k.P2b), k.P2c);
     }
-    uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
-    uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, st[0]);      // lane+1's bottom pair
+    // lanes without a source keep the first operand: BIG at the ends of a 16-lane row; with narrower groups the
+    // end lanes are overridden below anyway, so the move needs no initialised destination
+    uint32_t below = LPP < 16 ? dpp_row_any<DPP_ROW_SHR1>(st[NP - 1]) : dpp_row<DPP_ROW_SHR1>(BIG, st[NP - 1]); // lane-1's top pair
+    uint32_t above = LPP < 16 ? dpp_row_any<DPP_ROW_SHL1>(st[0]) : dpp_row<DPP_ROW_SHL1>(BIG, st[0]);           // lane+1's bottom pair
     if (LPP < 16) {
         below = first ? BIG : below;
         above = last ? BIG : above;
@@ -718,8 +726,8 @@ __device__ __forceinline__ void cost_from_paths(const uint32_t (&T)[NP], const u
 {
     const uint32_t BIG = 0x7fff7fffu;
     const uint32_t mp2v = pk_adds(minP, k.P2a);
-    uint32_t below = dpp_row<DPP_ROW_SHR1>(BIG, P[NP - 1]);
-    uint32_t above = dpp_row<DPP_ROW_SHL1>(BIG, P[0]);
+    uint32_t below = LPP < 16 ? dpp_row_any<DPP_ROW_SHR1>(P[NP - 1]) : dpp_row<DPP_ROW_SHR1>(BIG, P[NP - 1]);
+    uint32_t above = LPP < 16 ? dpp_row_any<DPP_ROW_SHL1>(P[0]) : dpp_row<DPP_ROW_SHL1>(BIG, P[0]);
     if (LPP < 16) {
         below = first ? BIG : below;
         above = last ? BIG : above;
