@@ -1427,6 +1427,12 @@ struct l3d_sgbm {
     SgbmGeom g;
     int device = 0, max_batch = 0, last_batch = 0;
     hipStream_t stream = nullptr;
+    // A batch runs as two halves on two streams of the handle's own, forked from and joined to the caller's
+    // stream by events: the scan kernels of one half overlap the tails and the memory-bound phases of the other
+    // (measured 7 % faster at 256 frames).  Off with L3D_SGBM_SPLIT=0, below kSplitMinBatch, and while profiling.
+    hipStream_t sub[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool split = true;
     uint8_t *in_left = nullptr, *in_right = nullptr; // staging for the host entry point
     int16_t *out_disp = nullptr;
     uint2 *lrec = nullptr;
@@ -1483,6 +1489,11 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     for (auto &set : h->ev)
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : h->sub)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_join)
+        if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1539,6 +1550,10 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     const size_t vol = g.W1 > 0 ? B * height * (size_t)g.W1 * g.Dp * sizeof(int16_t) : 0;
     const size_t cols = g.W1 > 0 ? B * height * (size_t)g.W1 : 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming);
+    if (const char *ov = std::getenv("L3D_SGBM_SPLIT")) h->split = std::atoi(ov) != 0;
     // every buffer is cleared once here: the first write to fresh device memory pays for mapping its
     // pages, and that belongs to set-up, not to the first compute call
     auto alloc = [&](void **ptr, size_t bytes) {
@@ -1567,7 +1582,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->labels, B * px * 4);
         alloc((void **)&h->sizes, B * px * 4);
         alloc((void **)&h->tsizes, B * px * 4);
-        alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, STH) * 256 + 1) * sizeof(int)); // [0] = count, then the list
+        alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, STH) * 256 + 2) * sizeof(int)); // per part of a batch: [0] = count, then the list
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -1637,34 +1652,39 @@ static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &
     return L3D_OK;
 }
 
-static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
+// The handle's buffers from frame `f0` on: every buffer is laid out frame by frame, so a part of a batch runs on the
+// same kernels with advanced base pointers and leaves exactly what the whole batch would have left.
+static l3d_sgbm sgbm_view(const l3d_sgbm *h, int f0, int part)
+{
+    l3d_sgbm v = *h;
+    const SgbmGeom &g = h->g;
+    const size_t f = (size_t)f0, px = (size_t)g.W * g.H, cols = (size_t)g.H * g.W1, colw = (size_t)g.Dp / 2;
+    v.prof = false;
+    v.lrec += f * px;
+    v.rrev += f * 6 * px;
+    if (g.tonly) {
+        v.Tvol += f * g.HR * g.W1 * colw;
+        v.Mvol += f * g.HR * g.W1;
+    } else {
+        v.Cvol += f * cols * colw;
+        v.Tvol += f * cols * colw;
+    }
+    v.Lvol += f * g.H * (size_t)cdiv(g.W1, 4) * colw;
+    v.wta += f * cols;
+    v.dsub += f * cols;
+    v.raw += f * px;
+    if (v.labels) {
+        v.labels += f * px; v.sizes += f * px; v.tsizes += f * px;
+        v.pend += f * cdiv(g.W, ST) * cdiv(g.H, STH) * 256 + part;   // each part: [0] = count, then its list
+    }
+    return v;
+}
+
+// prefilter ... speckle filter of B frames on stream s; `stamp` marks the kernel boundaries for the per-kernel timing
+template <typename Stamp>
+static int sgbm_run_part(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
 {
     const SgbmGeom &g = h->g;
-    const size_t px = (size_t)g.W * g.H;
-    const size_t n = px * B;
-    h->last_batch = B;
-    if (g.W1 <= 0) {
-        // no column has a full disparity range: the whole map is invalid
-        // (median of a constant image and the speckle filter leave it unchanged)
-        std::vector<int16_t> fill(n, (int16_t)g.invalid16);
-        L3D_HIP_CHECK(hipMemcpyAsync(d_disp, fill.data(), n * 2, hipMemcpyHostToDevice, s));
-        L3D_HIP_CHECK(hipStreamSynchronize(s));
-        return L3D_OK;
-    }
-    int slot = -1;
-    if (h->prof) {
-        if (h->ev_pending == l3d_sgbm::RING) {
-            int rc = sgbm_prof_drain_one(h);
-            if (rc) return rc;
-        }
-        slot = h->ev_head;
-        h->ev_head = (h->ev_head + 1) % l3d_sgbm::RING;
-        h->ev_pending++;
-    }
-    int mark = 0;
-    auto stamp = [&]() {
-        if (slot >= 0) (void)hipEventRecord(h->ev[slot][mark++], s);
-    };
     stamp();
     hipLaunchKernelGGL(k_prefilter, dim3(cdiv(cdiv(g.W, 4) * g.H, 256), 1, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
@@ -1683,6 +1703,59 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
         if (rc) return rc;
     }
     stamp();
+    return L3D_OK;
+}
+
+constexpr int kSplitMinBatch = 8;
+
+static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
+{
+    const SgbmGeom &g = h->g;
+    const size_t px = (size_t)g.W * g.H;
+    const size_t n = px * B;
+    h->last_batch = B;
+    if (g.W1 <= 0) {
+        // no column has a full disparity range: the whole map is invalid
+        // (median of a constant image and the speckle filter leave it unchanged)
+        std::vector<int16_t> fill(n, (int16_t)g.invalid16);
+        L3D_HIP_CHECK(hipMemcpyAsync(d_disp, fill.data(), n * 2, hipMemcpyHostToDevice, s));
+        L3D_HIP_CHECK(hipStreamSynchronize(s));
+        return L3D_OK;
+    }
+    if (h->split && !h->prof && B >= kSplitMinBatch) {
+        // fork: both halves start when the caller's stream gets here; join: the caller's stream goes on after both
+        L3D_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+        constexpr int nchunk = 2;   // more parts per stream measured slower (4: +0.7 %, 8: +5 %)
+        auto no_stamp = []() {};
+        for (int i = 0; i < 2; i++) L3D_HIP_CHECK(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+        for (int c = 0, f0 = 0; c < nchunk; c++) {
+            const int nb = (B * (c + 1)) / nchunk - (B * c) / nchunk;
+            l3d_sgbm v = sgbm_view(h, f0, c);
+            const int rc = sgbm_run_part(&v, d_left + f0 * px, d_right + f0 * px, nb, d_disp + f0 * px, h->sub[c & 1], no_stamp);
+            if (rc) return rc;
+            f0 += nb;
+        }
+        for (int i = 0; i < 2; i++) L3D_HIP_CHECK(hipEventRecord(h->ev_join[i], h->sub[i]));
+        for (int i = 0; i < 2; i++) L3D_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        L3D_HIP_CHECK(hipGetLastError());
+        return L3D_OK;
+    }
+    int slot = -1;
+    if (h->prof) {
+        if (h->ev_pending == l3d_sgbm::RING) {
+            int rc = sgbm_prof_drain_one(h);
+            if (rc) return rc;
+        }
+        slot = h->ev_head;
+        h->ev_head = (h->ev_head + 1) % l3d_sgbm::RING;
+        h->ev_pending++;
+    }
+    int mark = 0;
+    auto stamp = [&]() {
+        if (slot >= 0) (void)hipEventRecord(h->ev[slot][mark++], s);
+    };
+    const int rc = sgbm_run_part(h, d_left, d_right, B, d_disp, s, stamp);
+    if (rc) return rc;
     L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;
 }
