@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 64 for C3, 16 for C5)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--pipelines", type=int, default=1, help="independent pipelines (matcher + buffers + streams) the steps alternate between")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,44 +143,53 @@ def main():
     d_l = torch.from_numpy(lbgr).to(dev)
     d_r = torch.from_numpy(rbgr).to(dev)
 
-    left = stereo.StereoSGBM_create(minDisparity=0, numDisparities=D, blockSize=block, P1=8 * 3 * block ** 2,
-                                    P2=32 * 3 * block ** 2, disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100,
-                                    speckleRange=32, preFilterCap=63, mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY,
-                                    device=local_rank, max_batch=B)
-    right = wls = None
-    if use_wls:
-        right = stereo.createRightMatcher(left)
-        wls = stereo.createDisparityWLSFilter(left)
-        wls.setLambda(lam)
-        wls.setSigmaColor(sigma)
-    steger = FastStegerExtractor(3.0, 200, device=local_rank)
-    cap = 4 * H  # points kept per frame (the synthetic ridge yields ~1.6 per row)
+    # A pipeline = matcher (with its work buffers), output buffers and a pair of streams.  Frame batches are
+    # independent, so with --pipelines 2 consecutive steps alternate between two of them and step k+1 starts while
+    # step k drains; measured no better than one (the matcher already overlaps two half batches inside), the default.
+    def make_pipe():
+        p = {}
+        p["left"] = stereo.StereoSGBM_create(minDisparity=0, numDisparities=D, blockSize=block, P1=8 * 3 * block ** 2,
+                                             P2=32 * 3 * block ** 2, disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100,
+                                             speckleRange=32, preFilterCap=63, mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY,
+                                             device=local_rank, max_batch=B)
+        p["right"] = p["wls"] = None
+        if use_wls:
+            p["right"] = stereo.createRightMatcher(p["left"])
+            p["wls"] = stereo.createDisparityWLSFilter(p["left"])
+            p["wls"].setLambda(lam)
+            p["wls"].setSigmaColor(sigma)
+        p["steger"] = FastStegerExtractor(3.0, 200, device=local_rank)
+        p["gl"] = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        p["gr"] = torch.empty_like(p["gl"])
+        p["disp"] = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+        p["dr"] = torch.empty_like(p["disp"])
+        p["df"] = torch.empty_like(p["disp"])
+        p["depth"] = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        # the laser extractor works on the colour frame alone: it runs beside the matcher on a stream of its own
+        p["main"] = torch.cuda.Stream()
+        p["side"] = torch.cuda.Stream()
+        return p
 
-    gl = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    gr = torch.empty_like(gl)
-    disp = torch.empty((B, H, W), dtype=torch.int16, device=dev)
-    dr_ = torch.empty_like(disp)
-    df_ = torch.empty_like(disp)
-    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    cap = 4 * H  # points kept per frame (the synthetic ridge yields ~1.6 per row)
+    pipes = [make_pipe() for _ in range(max(1, args.pipelines))]
+    left, right, steger = pipes[0]["left"], pipes[0]["right"], pipes[0]["steger"]
     state = {}
 
-    # the laser extractor works on the colour frame alone: it runs beside the matcher on a stream of its own
-    main_stream = torch.cuda.current_stream()
-    side_stream = torch.cuda.Stream()
-
-    def step():
-        side_stream.wait_stream(main_stream)
-        with torch.cuda.stream(side_stream):
-            state["xy"], state["counts"] = steger.extract_device(d_l, cap)
-        ops.bgr2gray_device(d_l, gl)
-        ops.bgr2gray_device(d_r, gr)
-        left.compute_device(gl, gr, disp)
-        d = disp
-        if use_wls:
-            right.compute_device(gr, gl, dr_)
-            d = wls.filter_device(disp, gl, dr_, df_)
-        ops.depth_from_disparity16_device(d, Q, depth)
-        main_stream.wait_stream(side_stream)
+    def step(k=0, beside=True):
+        p = pipes[k % len(pipes)]
+        with torch.cuda.stream(p["main"]):
+            p["side"].wait_stream(p["main"])
+            with torch.cuda.stream(p["side"] if beside else p["main"]):
+                state["xy"], state["counts"] = p["steger"].extract_device(d_l, cap)
+            ops.bgr2gray_device(d_l, p["gl"])
+            ops.bgr2gray_device(d_r, p["gr"])
+            p["left"].compute_device(p["gl"], p["gr"], p["disp"])
+            d = p["disp"]
+            if use_wls:
+                p["right"].compute_device(p["gr"], p["gl"], p["dr"])
+                d = p["wls"].filter_device(p["disp"], p["gl"], p["dr"], p["df"])
+            ops.depth_from_disparity16_device(d, Q, p["depth"])
+            p["main"].wait_stream(p["side"])
 
     def fence():
         torch.cuda.synchronize()
@@ -187,12 +197,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        step()
+    for k in range(max(args.warmup, len(pipes))):
+        step(k)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -208,7 +218,7 @@ def main():
     if right is not None:
         right.profile(True)
     for _ in range(args.steps):
-        step()
+        step(0, beside=False)   # nothing beside the kernel being timed
     fence()
     prof = left.profile_read()
     left.profile(False)
@@ -272,7 +282,8 @@ def main():
             "vs_baseline": None, "dtype": "s16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} rectified pairs, SGBM-3WAY D={D} block={block}"
                                    + (f" + right matcher + WLS lambda={lam:g}" if use_wls else "")
-                                   + " + depth + Steger sigma=3.0", "batch_per_gpu": B, "sharding": f"frames x{world}"},
+                                   + " + depth + Steger sigma=3.0", "batch_per_gpu": B, "sharding": f"frames x{world}",
+                       "pipelines_in_flight": len(pipes)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "timing": "HIP events around each kernel, second pass of the same steps with whole-batch launches on one stream"},
