@@ -79,7 +79,10 @@ void l3d_sgbm_destroy(l3d_sgbm *h);
  * img_stride in bytes; disp is [batch][H][W] int16, contiguous. */
 int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int batch,
                      ptrdiff_t row_stride, ptrdiff_t img_stride, int16_t *disp);
-/* same, device-resident operands */
+/* same, device-resident operands.  The work is ordered on `stream` as seen from outside: it starts when `stream`
+ * reaches the call and `stream` continues when the result is complete.  From 8 frames on, a batch runs as two
+ * halves on two streams owned by the handle, forked from and joined to `stream` by events (environment
+ * L3D_SGBM_SPLIT=0 keeps everything on `stream`).  One call at a time per handle. */
 int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch,
                             int16_t *d_disp, void *stream);
 
