@@ -139,6 +139,40 @@ def test_sgbm_batch_equals_single_frames(gpu, O):
     assert np.array_equal(m.compute(gl[4], gr[4]), batched[4])
 
 
+def test_sgbm_two_stream_halves_equal_whole_batch_and_oracle(gpu, O, monkeypatch):
+    """From 8 frames on the matcher runs a batch as two halves on two streams of its own.  An odd batch (unequal
+    halves, speckle filter on, so both halves keep their own pending-component lists) must give, frame by frame, what
+    the oracle gives, what the same handle gives for a batch below the threshold, and what a handle with the split
+    switched off gives; a second call on the same handle with a smaller split batch must not see stale state."""
+    W, H, D = 320, 180, 64
+    B = 11
+    frames = [_pair(W, H, D, 20 + k) for k in range(B)]
+    gl = np.stack([O.bgr2gray(f[0]) for f in frames])
+    gr = np.stack([O.bgr2gray(f[1]) for f in frames])
+    kw = _ref_ctor(D, 5)
+    m = _sgbm(**kw, max_batch=B)
+    split = m.compute(gl, gr)
+    p = O.sgbm_params(**kw)
+    for k in range(B):
+        assert np.array_equal(split[k], O.sgbm_compute(p, gl[k], gr[k])), f"frame {k}"
+    assert np.array_equal(m.compute(gl[:9], gr[:9]), split[:9])          # 4 + 5 frames
+    assert np.array_equal(m.compute(gl[2:7], gr[2:7]), split[2:7])       # below the threshold: one stream
+    monkeypatch.setenv("L3D_SGBM_SPLIT", "0")
+    whole = _sgbm(**kw, max_batch=B).compute(gl, gr)
+    assert np.array_equal(whole, split)
+    monkeypatch.delenv("L3D_SGBM_SPLIT")
+    # device-resident entry point on a side stream: the caller's stream order is kept across the fork and join
+    import torch
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dl, dr = torch.from_numpy(gl).to(dev, non_blocking=False), torch.from_numpy(gr).to(dev, non_blocking=False)
+        out = m.compute_device(dl, dr)
+        doubled = out.to(torch.int32) * 2            # consumer on the caller's stream, right behind the join
+    side.synchronize()
+    assert np.array_equal(doubled.cpu().numpy(), split.astype(np.int32) * 2)
+
+
 def test_sgbm_edge_cases(gpu, O):
     N = gpu
     # narrower than the disparity range: all invalid
