@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     float *bl = hrow + GH * BW;     // [BH][BW]
     float *tp = bl + BH * BW;       // [ks]
     volatile int &any_bright = *reinterpret_cast<volatile int *>(tp + ks);
+    int *xrange = reinterpret_cast<int *>(tp + ks) + 1;   // [2]: first and last tile column with a bright pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         return gray_at(im, a, x, y);
     };
 
-    if (tid == 0) any_bright = 0;
+    if (tid == 0) { any_bright = 0; xrange[0] = TW; xrange[1] = -1; }
     __syncthreads();
     // own pixels: brightness test on the unblurred gray value
     int own[4];
@@ -163,7 +164,14 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         else own[k] = inside ? gray_at(im, a, x, y) : -1;
         bright |= own[k] > a.thr;
     }
-    if (__ballot(bright) != 0ull && lane == 0) any_bright = 1;
+    {
+        const unsigned long long bm = __ballot(bright);
+        if (bm != 0ull && lane == 0) {
+            any_bright = 1;
+            atomicMin(&xrange[0], __ffsll((long long)bm) - 1);
+            atomicMax(&xrange[1], 63 - __clzll((long long)bm));
+        }
+    }
     __syncthreads();
     if (!any_bright) {
         if (lane == 0) {
@@ -177,29 +185,33 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     }
 
     for (int i = tid; i < ks; i += 256) tp[i] = taps[i];
+    // Only the columns around the bright pixels are blurred (a laser line crosses a tile in a few columns): blurred
+    // columns b0 .. b0+nb-1 of the tile's BW, from gray columns b0 .. b0+nb+2R-1 of its GW.  Every value is
+    // computed as it would be for the whole tile.
+    const int b0 = xrange[0], nb = xrange[1] - xrange[0] + 1 + 2 * HB, ng = nb + 2 * R;
     // gray tile with halo; coordinates outside the region are mirrored (BORDER_REFLECT_101)
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int gy = i / GW, gx = i - gy * GW;
+    for (int i = tid; i < GH * ng; i += 256) {
+        const int gy = i / ng, gx = b0 + (i - gy * ng);
         const int x = reflect101(tx0 - HB - R + gx, a.rw), y = reflect101(ty0 - HB - R + gy, a.rh);
-        gt[i] = (float)src_at(x, y);
+        gt[gy * GW + gx] = (float)src_at(x, y);
     }
     __syncthreads();
     // row pass: taps accumulated left to right
-    for (int i = tid; i < GH * BW; i += 256) {
-        const int gy = i / BW, bx = i - gy * BW;
+    for (int i = tid; i < GH * nb; i += 256) {
+        const int gy = i / nb, bx = b0 + (i - gy * nb);
         const float *src = gt + gy * GW + bx;
         float s = 0.0f;
         for (int k = 0; k < ks; k++) s = s + tp[k] * src[k];
-        hrow[i] = s;
+        hrow[gy * BW + bx] = s;
     }
     __syncthreads();
     // column pass: centre tap, then symmetric pairs
-    for (int i = tid; i < BH * BW; i += 256) {
-        const int by = i / BW, bx = i - by * BW;
+    for (int i = tid; i < BH * nb; i += 256) {
+        const int by = i / nb, bx = b0 + (i - by * nb);
         const float *src = hrow + (by + R) * BW + bx;
         float s = tp[R] * src[0];
         for (int k = 1; k <= R; k++) s = s + tp[R + k] * (src[-k * BW] + src[k * BW]);
-        bl[i] = s;
+        bl[by * BW + bx] = s;
     }
     __syncthreads();
 
@@ -473,7 +485,7 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
     }
     const int R = a.R, HB = variant == VAR_FAST ? 1 : 2;
     const size_t lds = ((size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB + 2 * R) + (size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB) +
-                        (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 1) * sizeof(float);
+                        (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 3) * sizeof(float);
     const dim3 grid(a.ntx, a.nty, B);
     switch (variant) {
     case VAR_FAST: hipLaunchKernelGGL(k_steger_tile<VAR_FAST>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
