@@ -215,11 +215,31 @@ class SingleUSBStereoCameraManager:
             return self.wls_filter.filter(disparity_left, left_gray, disparity_map_right=disparity_right)
         return disparity_left
 
+    def _depth_on_device(self, gl, gr):
+        """(B,H,W) uint8 gray tensors on the GPU -> float32 depth tensor; nothing leaves the device in between."""
+        if self.stereo_matcher is None:
+            self._initialize_stereo_matcher_optimized()
+        d = self.stereo_matcher.compute_device(gl, gr)
+        if self.use_wls and self.wls_filter is not None:
+            dr = self.right_matcher.compute_device(gr, gl)
+            d = self.wls_filter.filter_device(d, gl, dr)
+        return ops.depth_from_disparity16_device(d, self.Q)
+
+    def _upload(self, img: np.ndarray):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(img)).to(torch.device("cuda", self.device))
+
     def compute_depth(self, left_img: np.ndarray, right_img: np.ndarray) -> np.ndarray:
         """Depth map (float32, Q units, 0 = invalid) of a rectified BGR or gray pair; the body of
-        the reference's get_frames from the gray conversion on (:319-357)."""
-        disp16 = self.compute_disparity(left_img, right_img)
-        return ops.depth_from_disparity16(disp16, self.Q, device=self.device)
+        the reference's get_frames from the gray conversion on (:319-357).  One upload of the pair, one download
+        of the depth map: the stages in between hand device buffers to each other."""
+        if left_img.shape != right_img.shape or left_img.dtype != np.uint8 or right_img.dtype != np.uint8:
+            raise ValueError("compute_depth expects two uint8 images of one shape")
+        L, R = self._upload(left_img)[None], self._upload(right_img)[None]
+        gl = ops.bgr2gray_device(L) if L.dim() == 4 else L
+        gr = ops.bgr2gray_device(R) if R.dim() == 4 else R
+        return self._depth_on_device(gl, gr)[0].cpu().numpy()
 
     def get_frames(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
         if self.cap is None or not self.cap.isOpened():
@@ -227,10 +247,24 @@ class SingleUSBStereoCameraManager:
         ret, frame = self.cap.read()
         if not ret:
             return None, None
-        left_img, right_img = self._split_frame(frame)
-        left_rectified, right_rectified = self.rectify_pair(left_img, right_img)
-        depth_map = self.compute_depth(left_rectified, right_rectified)
-        return left_rectified, depth_map
+        if (not self._ensure_rectifiers() or frame.ndim != 3 or frame.shape[2] != 3 or frame.dtype != np.uint8
+                or (frame.shape[1] // 2 if self.split_mode == 'horizontal' else frame.shape[1]) != self.single_width
+                or (frame.shape[0] if self.split_mode == 'horizontal' else frame.shape[0] // 2) != self.single_height):
+            left_img, right_img = self._split_frame(frame)
+            left_rectified, right_rectified = self.rectify_pair(left_img, right_img)
+            return left_rectified, self.compute_depth(left_rectified, right_rectified)
+        # The combined frame is uploaded once; each eye is remapped straight out of it (the right eye starts half a
+        # row, or half a frame, further on), the gray planes come out of the remap, and only the rectified left
+        # image and the depth map are downloaded (reference :312-357).
+        F = self._upload(frame)[None]
+        fh, fw, ch = frame.shape
+        w, h = self.single_width, self.single_height
+        right_off = w * ch if self.split_mode == 'horizontal' else h * fw * ch
+        view = dict(row_stride=fw * ch, img_stride=fh * fw * ch, src_size=(w, h))
+        left_rect, gl = self.rectifier_left.remap_device(F, want_bgr=True, want_gray=True, **view)
+        _, gr = self.rectifier_right.remap_device(F, want_bgr=False, want_gray=True, offset_bytes=right_off, **view)
+        depth = self._depth_on_device(gl, gr)
+        return left_rect[0].cpu().numpy(), depth[0].cpu().numpy()
 
     def get_camera_intrinsics(self) -> Optional[Dict]:
         if self.camera_matrix_left is None:
