@@ -1527,6 +1527,12 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     sgbm_make_geom(p, width, height, &h->g);
     h->device = device;
     h->max_batch = max_batch;
+    // A handle for single frames (a live camera) has too few image rows to fill the chip either way; there 16 lanes
+    // per row (twice the waves, a shorter step per column) give the lower latency: 0.87 -> 0.76 ms per 640x360 pair.
+    if (max_batch <= 4 && h->g.Dp == h->g.D && h->g.D % 32 == 0 && h->g.LPPh == 8 && !std::getenv("L3D_SGBM_LPPH")) {
+        h->g.LPPh = 16;
+        h->g.NPh = h->g.Dp / 32;
+    }
     const SgbmGeom &g = h->g;
     if (g.W1 > 0 && g.stripe_overlap > g.stripe_sz) {
         delete h;
