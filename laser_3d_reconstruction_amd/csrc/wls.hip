@@ -135,6 +135,11 @@ __global__ void __launch_bounds__(256) k_transpose2(const float *__restrict__ in
 
 // Thomas algorithm down every column of a [B][n][m] plane pair (m lines of length n, adjacent
 // lines adjacent in memory).  w[i] is the (negative) weight between element i and i+1.
+// One thread solves one line, in the operation order of the sequential definition.  The recurrences are short
+// dependent chains, so what a thread would wait for is memory: the operands of FGS_CHUNK elements are requested
+// together, one chunk ahead of their use, instead of one element at a time.
+constexpr int FGS_CHUNK = 8;
+
 __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
                                                   float *__restrict__ inter, int n, int m, float lambda)
 {
@@ -145,26 +150,61 @@ __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float 
     float *a1 = u1 + base, *a2 = u2 + base, *it = inter + base;
     const float *ww = w + base;
     float lower = 0.0f, prev_inter = 0.0f, p1 = 0.0f, p2 = 0.0f;
-    for (int i = 0; i < n; i++) {
-        const size_t o = (size_t)i * m;
-        const float upper = lambda * ww[o];
-        const float denom = (1.0f - lower - upper) - lower * prev_inter;
-        const float ci = upper / denom;
-        const float v1 = (a1[o] - lower * p1) / denom;
-        const float v2 = (a2[o] - lower * p2) / denom;
-        it[o] = ci;
-        a1[o] = v1;
-        a2[o] = v2;
-        prev_inter = ci; p1 = v1; p2 = v2;
-        lower = upper;
+    float cw[FGS_CHUNK], c1[FGS_CHUNK], c2[FGS_CHUNK], nw[FGS_CHUNK], n1[FGS_CHUNK], n2[FGS_CHUNK];
+    auto load_fwd = [&](int i0, float (&xw)[FGS_CHUNK], float (&x1)[FGS_CHUNK], float (&x2)[FGS_CHUNK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) {
+            const size_t o = (size_t)min(i0 + k, n - 1) * m;   // clamped: the tail of the last chunk is loaded, not used
+            xw[k] = ww[o]; x1[k] = a1[o]; x2[k] = a2[o];
+        }
+    };
+    load_fwd(0, cw, c1, c2);
+    for (int i0 = 0; i0 < n; i0 += FGS_CHUNK) {
+        if (i0 + FGS_CHUNK < n) load_fwd(i0 + FGS_CHUNK, nw, n1, n2);
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) {
+            const int i = i0 + k;
+            if (i < n) {
+                const size_t o = (size_t)i * m;
+                const float upper = lambda * cw[k];
+                const float denom = (1.0f - lower - upper) - lower * prev_inter;
+                const float ci = upper / denom;
+                const float v1 = (c1[k] - lower * p1) / denom;
+                const float v2 = (c2[k] - lower * p2) / denom;
+                it[o] = ci;
+                a1[o] = v1;
+                a2[o] = v2;
+                prev_inter = ci; p1 = v1; p2 = v2;
+                lower = upper;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) { cw[k] = nw[k]; c1[k] = n1[k]; c2[k] = n2[k]; }
     }
-    for (int i = n - 2; i >= 0; i--) {
-        const size_t o = (size_t)i * m;
-        const float ci = it[o];
-        p1 = a1[o] - ci * p1;
-        p2 = a2[o] - ci * p2;
-        a1[o] = p1;
-        a2[o] = p2;
+    // back substitution from element n-2 down; the values it reads were written above by this same thread
+    auto load_bwd = [&](int i0, float (&xw)[FGS_CHUNK], float (&x1)[FGS_CHUNK], float (&x2)[FGS_CHUNK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) {
+            const size_t o = (size_t)max(i0 - k, 0) * m;
+            xw[k] = it[o]; x1[k] = a1[o]; x2[k] = a2[o];
+        }
+    };
+    if (n >= 2) load_bwd(n - 2, cw, c1, c2);
+    for (int i0 = n - 2; i0 >= 0; i0 -= FGS_CHUNK) {
+        if (i0 - FGS_CHUNK >= 0) load_bwd(i0 - FGS_CHUNK, nw, n1, n2);
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) {
+            const int i = i0 - k;
+            if (i >= 0) {
+                const size_t o = (size_t)i * m;
+                p1 = c1[k] - cw[k] * p1;
+                p2 = c2[k] - cw[k] * p2;
+                a1[o] = p1;
+                a2[o] = p2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FGS_CHUNK; k++) { cw[k] = nw[k]; c1[k] = n1[k]; c2[k] = n2[k]; }
     }
 }
 
