@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_transpose2(const float *__restrict__ in
 // One thread solves one line, in the operation order of the sequential definition.  The recurrences are short
 // dependent chains, so what a thread would wait for is memory: the operands of FGS_CHUNK elements are requested
 // together, one chunk ahead of their use, instead of one element at a time.
-constexpr int FGS_CHUNK = 8;
+constexpr int FGS_CHUNK = 16;
 
 __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
                                                   float *__restrict__ inter, int n, int m, float lambda)
