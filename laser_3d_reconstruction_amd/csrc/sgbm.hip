@@ -395,7 +395,7 @@ __host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 2
 __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D)
 {
     const int tileC = 256 / LPP + 2 * SW2;
-    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (size_t)(2 * SH2 + 2) * 256 * NP;
+    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (size_t)(2 * SH2 + 1) * 256 * NP;
 }
 struct __attribute__((packed, aligned(1))) UnalignedPair {
     uint32_t lo, hi;
@@ -431,7 +431,9 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     const int end = min((n + 1) * g.stripe_sz, H);
     const int own0 = n * g.stripe_sz;
     if (start >= end) return;
-    const int NR = 2 * SH2 + 2;
+    // ring of box-sum rows: the 2*SH2+1 rows of the vertical window.  The row entering the window takes the slot of
+    // the row leaving it, which is therefore read first (slots are thread-private: no barrier involved).
+    const int NR = 2 * SH2 + 1;
     const int tileC = GPB + 2 * SW2;
     const int nd = (tileC - 1 + g.Dp + 3) / 4 + 1;  // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
@@ -610,6 +612,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         Tout += row_bytes;
         Mout += W1;
         if (y + 1 < end) {
+            const Pack<NP> sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
             if (box_now) {
                 box_row(slot_add, y & 1);
                 box_sum(slot_add);
@@ -618,7 +621,6 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = o.v[p];
             }
-            const Pack<NP> sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
 #pragma unroll
             for (int p = 0; p < NP; p++) Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub.v[p]);
             slot_add = slot_add + 1 == NR ? 0 : slot_add + 1;
