@@ -57,6 +57,9 @@ struct SgbmGeom {
     // for stripe 0), so "the previous row" of every image row is always the row above it.  The horizontal
     // kernel gets C back as T - (what the recurrence added), which is exact as long as nothing saturates.
     int tonly, HR;
+    // vertical kernel: the ring of box-sum rows lives in registers (a kernel variant built for this block size)
+    // instead of LDS
+    int ring_regs;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -392,10 +395,10 @@ __host__ __device__ inline int vertical_copy_stride(int tileC, int D)
     return (w + 3) / 4 * 4 + 2;
 }
 __host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 2 * vertical_copy_stride(tileC, D) + 6 * tileC; }
-__host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D)
+__host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D, bool ring_in_regs = false)
 {
     const int tileC = 256 / LPP + 2 * SW2;
-    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (size_t)(2 * SH2 + 1) * 256 * NP;
+    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * 256 * NP);
 }
 struct __attribute__((packed, aligned(1))) UnalignedPair {
     uint32_t lo, hi;
@@ -413,7 +416,10 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // left pixel are staged as ready-made 16-bit splats for the same reason.
 // Every global access is (block-uniform 64-bit base) + (per-lane 32-bit offset fixed for the whole
 // kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
-template <int NP, int LPP, bool PAD>
+// CSH2 > 0: a variant for block size 2*CSH2+1 that keeps the ring of box-sum rows in registers, as a shift register
+// of the 2*CSH2+1 rows of the vertical window (rows above the stripe's first row are copies of it).  With block sizes
+// from 7 on the ring in LDS (42 KB and more per block) leaves two blocks per CU; in registers it leaves three.
+template <int NP, int LPP, bool PAD, int CSH2 = 0>
 __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
@@ -556,14 +562,18 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 #pragma unroll
             for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px.v[p]);
         }
-        Pack<NP> o;
+        if (CSH2 == 0) {
+            Pack<NP> o;
 #pragma unroll
-        for (int p = 0; p < NP; p++) o.v[p] = hs[p];
-        *reinterpret_cast<Pack<NP> *>(ring + (slot * 256 + tid) * NP) = o;
+            for (int p = 0; p < NP; p++) o.v[p] = hs[p];
+            *reinterpret_cast<Pack<NP> *>(ring + (slot * 256 + tid) * NP) = o;
+        }
     };
 
     // cost of the stripe's first row: rows above it replicate that row
-    for (int k = start; k <= start + SH2; k++) {
+    constexpr int RNR = CSH2 > 0 ? 2 * CSH2 + 1 : 1;
+    uint32_t rr[RNR][NP];   // CSH2 > 0: box sums of rows y-SH2 .. y+SH2, oldest first
+    auto first_rows = [&](int k, int j) __attribute__((always_inline)) {
         const int kk = min(k, H - 1);
         stage_fetch(kk);
         lds_barrier();            // the previous row's stage reads are done
@@ -573,6 +583,20 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         const int scale = (k == start) ? SH2 + 1 : 1;
 #pragma unroll
         for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pk_mul(hs[p], scale));
+        if (CSH2 > 0) {
+#pragma unroll
+            for (int r = 0; r < RNR; r++)
+                if (j == 0 ? r <= CSH2 : r == CSH2 + j) {
+#pragma unroll
+                    for (int p = 0; p < NP; p++) rr[r][p] = hs[p];
+                }
+        }
+    };
+    if (CSH2 > 0) {
+#pragma unroll
+        for (int j = 0; j <= CSH2; j++) first_rows(start + j, j);
+    } else {
+        for (int k = start; k <= start + SH2; k++) first_rows(k, 0);
     }
 
     const uint32_t voff = (uint32_t)(((size_t)xc_own * CW + l * NP) * sizeof(uint32_t));
@@ -612,14 +636,32 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         Tout += row_bytes;
         Mout += W1;
         if (y + 1 < end) {
-            const Pack<NP> sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
+            Pack<NP> sub;
+            if (CSH2 > 0) {
+#pragma unroll
+                for (int p = 0; p < NP; p++) sub.v[p] = rr[0][p];
+            } else
+                sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
             if (box_now) {
                 box_row(slot_add, y & 1);
                 box_sum(slot_add);
+            } else if (CSH2 > 0) {
+                // below the last image row: that row again, the newest entry of the shift register
+#pragma unroll
+                for (int p = 0; p < NP; p++) hs[p] = rr[RNR - 1][p];
             } else {
                 const Pack<NP> o = *reinterpret_cast<const Pack<NP> *>(ring + (slot_last * 256 + tid) * NP);
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = o.v[p];
+            }
+            if (CSH2 > 0) {
+#pragma unroll
+                for (int r = 0; r + 1 < RNR; r++) {
+#pragma unroll
+                    for (int p = 0; p < NP; p++) rr[r][p] = rr[r + 1][p];
+                }
+#pragma unroll
+                for (int p = 0; p < NP; p++) rr[RNR - 1][p] = hs[p];
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub.v[p]);
@@ -1404,6 +1446,14 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
 
 using namespace l3d;
 
+// The vertical kernel has variants with the ring of box-sum rows in registers for 96 disparities on 8 lanes and 128 on
+// 16 lanes, block sizes 7, 9 and 11 (the reference's own default for frames from 400 px of width is 96 / 7).
+static bool vertical_ring_in_regs(const SgbmGeom &g)
+{
+    const bool shape = g.Dp == g.D && ((g.NPv == 6 && g.LPPv == 8) || (g.NPv == 4 && g.LPPv == 16));
+    return shape && g.SH2 >= 3 && g.SH2 <= 5 && g.SW2 == g.SH2;
+}
+
 // Calls f(integral_constant<NP>, integral_constant<LPP>) for the built kernel variant; false if there is none.
 template <typename F>
 static bool dispatch_variant(int NP, int LPP, bool pad, F &&f)
@@ -1542,7 +1592,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
                   height, p->blockSize, g.stripe_overlap, g.stripe_sz);
         return L3D_ERR_UNSUPPORTED;
     }
-    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.Dp) * sizeof(uint32_t);
+    h->g.ring_regs = vertical_ring_in_regs(g) && !(std::getenv("L3D_SGBM_RING_REGS") && std::atoi(std::getenv("L3D_SGBM_RING_REGS")) == 0);
+    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.Dp, g.ring_regs != 0) * sizeof(uint32_t);
     if (vertical_stage_roles(256 / g.LPPv + 2 * g.SW2, g.Dp) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
         delete h;
         set_error("l3d_sgbm_create: image %dx%d with %d disparities exceeds the input staging of the vertical kernel", width, height, g.D);
@@ -1621,6 +1672,17 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
+    if constexpr (!PAD && ((NP == 6 && LPP == 8) || (NP == 4 && LPP == 16))) {
+        // the block sizes with a register-ring variant (see vertical_ring_in_regs)
+        if (g.ring_regs) {
+            switch (g.SH2) {
+            case 3: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 3>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 4: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 4>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 5: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 5>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            default: break;
+            }
+        }
+    }
     hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
 }
 

@@ -79,6 +79,10 @@ def test_gray_bit_exact(gpu, O):
     (420, 40, 256, 5, 0, {}),                                          # the largest range
     (300, 64, 112, 19, 0, {}),                                         # 112 with a block whose ring needs the padded 16-lane form
     (280, 64, 96, 21, 0, {}),                                          # the largest block
+    (384, 160, 96, 7, 0, {}),                                          # the reference's own default for wide frames; with
+    (320, 128, 96, 11, 0, {}),                                         # (400,200,96,9) and (512,256,128,11) above: the vertical
+    (300, 120, 128, 9, 0, {}),                                         # kernel's variants with the box-sum ring in registers
+    (350, 97, 96, 7, -40, {}),                                         # ... ragged height, negative minDisparity
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
