@@ -83,6 +83,8 @@ def test_gray_bit_exact(gpu, O):
     (320, 128, 96, 11, 0, {}),                                         # (400,200,96,9) and (512,256,128,11) above: the vertical
     (300, 120, 128, 9, 0, {}),                                         # kernel's variants with the box-sum ring in registers
     (350, 97, 96, 7, -40, {}),                                         # ... ragged height, negative minDisparity
+    (260, 28, 96, 7, 0, {}),                                           # ... stripes barely taller than their overlap
+    (200, 40, 128, 11, 0, {}),
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
