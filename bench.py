@@ -32,6 +32,8 @@ CONFIGS = {
     "C2": (640, 360, 64, 5, False, 8000.0, 1.5),
     "C3": (1280, 720, 96, 9, True, 10000.0, 1.5),
     "C5": (1920, 1080, 128, 11, True, 8000.0, 1.5),
+    # what the reference's own constructor picks for a 640-px-wide eye (camera/single_usb_stereo_camera.py:239-282)
+    "REFDEFAULT": (640, 360, 96, 7, True, 8000.0, 1.5),
 }
 
 
@@ -128,7 +130,7 @@ def main():
     from laser_3d_reconstruction_amd.utils import synthetic as S
 
     W, H, D, block, use_wls, lam, sigma = CONFIGS[args.config]
-    B = args.batch if args.batch else {"C2": 256, "C3": 64, "C5": 16}.get(args.config, 64)
+    B = args.batch if args.batch else {"C2": 256, "C3": 64, "C5": 16, "REFDEFAULT": 128}.get(args.config, 64)
 
     # start-up: rank 0 owns the calibration and broadcasts it (the only collective of the job)
     calib = dict(make_rig(W, H), Q=make_Q(W, H)) if rank == 0 else None
