@@ -77,8 +77,15 @@ def cpu_baseline(W, H, D, block, use_wls, lam, sigma, seconds_budget=12.0):
         O.steger_extract(lb, 3.0, 200)
         t_total += time.perf_counter() - t0
         n += 1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": n / t_total, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n} synthetic {W}x{H} D={D} pairs, same stages as the GPU step, one thread of the C oracle"}
+            "sample": f"{n} synthetic {W}x{H} D={D} pairs, same stages as the GPU step, one thread of the C oracle",
+            "host": {"cpu_model": model, "os_cpu_count": os.cpu_count()}}
 
 
 def make_rig(W, H):
