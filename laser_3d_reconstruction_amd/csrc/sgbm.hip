@@ -557,11 +557,24 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     auto box_sum = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < NP; p++) hs[p] = 0;
-        for (int j = 0; j <= 2 * SW2; j++) {
-            const Pack<NP> px = *reinterpret_cast<const Pack<NP> *>(pixT + ((grp + j) * LPP + l) * NP);
+        // A loop that waits for each tile column exposes one LDS round trip per column: for block size 5, the common
+        // case, the five columns are read together before they are added.  (The same for the larger blocks of the
+        // register-ring variants, or in predicated groups of five for any size, costs more registers than it gains.)
+        if (SW2 == 2) {
+            Pack<NP> px[5];
 #pragma unroll
-            for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px.v[p]);
-        }
+            for (int j = 0; j < 5; j++) px[j] = *reinterpret_cast<const Pack<NP> *>(pixT + ((grp + j) * LPP + l) * NP);
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+#pragma unroll
+                for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px[j].v[p]);
+            }
+        } else
+            for (int j = 0; j <= 2 * SW2; j++) {
+                const Pack<NP> px = *reinterpret_cast<const Pack<NP> *>(pixT + ((grp + j) * LPP + l) * NP);
+#pragma unroll
+                for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px.v[p]);
+            }
         if (CSH2 == 0) {
             Pack<NP> o;
 #pragma unroll
