@@ -460,9 +460,8 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     auto tile_x = [&](int c) { return min(max(xa - SW2 + c, 0), W1 - 1) + g.minX1; };
     const int x_hi = tile_x(tileC - 1);
     const int rr_lo = W - 1 - x_hi + g.minD;        // mirrored index of the first staged right-image byte
-    // staging roles of this thread: which global word goes to which stage word
     // staging roles of this thread: every role fetches 8 bytes -- a word of a right-image plane run and the word after
-    // it (to cut the four shifted copies from), or one left record
+    // it (the copy that starts at byte 1 needs the first byte of the next word), or one left record
     uint32_t s_goff[kStageLoadsMax], s_lidx[kStageLoadsMax];
     bool s_left[kStageLoadsMax], s_on[kStageLoadsMax];
 #pragma unroll
