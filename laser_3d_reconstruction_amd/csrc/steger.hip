@@ -5,9 +5,9 @@
 // filter2D difference stencils, and the per-pixel Python loop that calls np.linalg.eig on the
 // 2x2 Hessian of every pixel brighter than the threshold.
 //
-// One fused kernel per 64x16 pixel tile:
-//   gray (u8) of the tile -> early exit when no pixel is above the threshold (the laser covers a
-//   few percent of a frame, so most tiles only cost their 3 B/pixel read) -> gray tile with
+// A streaming pass marks the 64x16 pixel tiles that hold a pixel above the threshold (the laser covers a few
+// percent of a frame) and a second kernel lists them; one fused kernel then works per listed tile:
+//   gray (u8) of the tile -> exact per-pixel brightness test (exit when none passes) -> gray tile with
 //   halo staged in LDS as float -> separable Gaussian through LDS -> stencils, closed-form 2x2
 //   symmetric eigen-decomposition in double, acceptance test -> per-row ballot compaction into
 //   fixed per-(row, tile) cells.
@@ -37,6 +37,7 @@ struct StegerArgs {
     int R;                // kernel radius (ksize = 2R+1)
     int thr;
     int ntx, nty;         // tiles per region
+    int ntiles;           // ntx * nty * batch
     double resp_thr;      // largest accepted |offset| of the improved variants
 };
 
@@ -123,10 +124,12 @@ __device__ __forceinline__ bool steger2_point(float dx, float dy, float dxx, flo
     return true;
 }
 
-// grid: (ntx, nty, batch); block 256 = 4 waves; wave w handles tile rows w, w+4, w+8, w+12
+// grid: blocks that walk the list of marked tiles (or, without a list, (ntx, nty, batch): one block per tile);
+// block 256 = 4 waves; wave w handles tile rows w, w+4, w+8, w+12
 template <int VAR>
 __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                     const float *__restrict__ taps, float2 *__restrict__ cells, int *__restrict__ cell_counts)
+                                                     const float *__restrict__ taps, float2 *__restrict__ cells, int *__restrict__ cell_counts,
+                                                     const int *__restrict__ tiles)
 {
     extern __shared__ float sm[];
     constexpr int HB = VAR == VAR_FAST ? 1 : 2;         // halo of the blurred tile that the derivative stencils reach
@@ -141,7 +144,19 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     int *xrange = reinterpret_cast<int *>(tp + ks) + 1;   // [2]: first and last tile column with a bright pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
+    for (int ti = tiles ? blockIdx.x : 0; ti < (tiles ? a.ntiles : 1); ti += gridDim.x) {
+    // the tile: an entry of the list of tiles with bright pixels (the list ends at the first -1), or (without a
+    // list) the block's own
+    int txi = blockIdx.x, tyi = blockIdx.y, b = blockIdx.z;
+    if (tiles) {
+        const int t = tiles[1 + a.ntiles + ti];
+        if (t < 0) break;
+        txi = t % a.ntx;
+        tyi = (t / a.ntx) % a.nty;
+        b = t / (a.ntx * a.nty);
+        __syncthreads();   // the previous tile's LDS is free
+    }
+    const int tx0 = txi * TW, ty0 = tyi * TH;
     const uint8_t *im = img + (size_t)b * a.W * a.H * a.channels;
     const uint8_t *mk = VAR == VAR_HYBRID ? mask + (size_t)b * a.W * a.H : nullptr;
     const size_t cell_base = ((size_t)b * a.rh) * a.ntx;
@@ -178,10 +193,10 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int y = ty0 + wv + 4 * k;
-                if (y < a.rh) cell_counts[cell_base + (size_t)y * a.ntx + blockIdx.x] = 0;
+                if (y < a.rh) cell_counts[cell_base + (size_t)y * a.ntx + txi] = 0;
             }
         }
-        return;
+        continue;
     }
 
     for (int i = tid; i < ks; i += 256) tp[i] = taps[i];
@@ -273,7 +288,7 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
             }
         }
         const unsigned long long m = __ballot(acc);
-        const size_t cell = cell_base + (size_t)y * a.ntx + blockIdx.x;
+        const size_t cell = cell_base + (size_t)y * a.ntx + txi;
         if (VAR == VAR_FAST || VAR == VAR_IMPROVED) {
             if (acc) {
                 const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -297,6 +312,44 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
             if (lane == 0) cell_counts[cell] = m != 0ull;
         }
     }
+    } // tiles
+}
+
+// Most tiles hold no bright pixel, and starting a 256-thread block per tile only to find that out took more than
+// half of the extraction time.  A streaming pass marks the tiles that have one (a thread tests four pixels of a row:
+// for the hybrid variant the mask, otherwise gray > threshold; the tile kernel repeats the exact test per pixel),
+// a second kernel turns the marks into a list, and the tile kernel walks that list.
+__global__ void __launch_bounds__(256) k_steger_mark(StegerArgs a, const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                     int *__restrict__ tiles)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
+    if (x >= a.rw) return;
+    const uint8_t *im = img + (size_t)b * a.W * a.H * a.channels;
+    bool bright = false;
+    if (!mask && a.channels == 3 && x + 4 <= a.rw) {
+        // the four pixels as three (unaligned) words instead of twelve bytes
+        uint32_t w[3];
+        __builtin_memcpy(w, im + ((size_t)(y + a.y0) * a.W + (x + a.x0)) * 3, 12);
+        auto byte = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            bright |= (int)((byte(3 * k + 2) * 9798u + byte(3 * k + 1) * 19235u + byte(3 * k) * 3735u + (1u << 14)) >> 15) > a.thr;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (x + k < a.rw) {
+                if (mask) bright |= mask[(size_t)b * a.W * a.H + (size_t)y * a.W + x + k] != 0;
+                else bright |= gray_at(im, a, x + k, y) > a.thr;
+            }
+        }
+    }
+    if (bright) tiles[1 + ((size_t)b * a.nty + y / TH) * a.ntx + x / TW] = 1;   // 4 | TW: the four pixels share a tile
+}
+
+__global__ void __launch_bounds__(256) k_steger_list(int ntiles, int *__restrict__ tiles)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ntiles && tiles[1 + t]) tiles[1 + ntiles + atomicAdd(&tiles[0], 1)] = t;
 }
 
 // per-row variants: the best candidate over the tiles of a row (first tile on ties) becomes the row's only point
@@ -371,6 +424,8 @@ struct l3d_steger {
     float *taps = nullptr;
     float2 *cells = nullptr;
     int *cell_counts = nullptr;
+    int *tile_list = nullptr;   // [0] = number of tiles that hold a bright pixel, then [max tiles] flags, then the list
+    size_t max_tiles = 0;
     // staging for the host entry point
     uint8_t *in = nullptr;
     float2 *out = nullptr;
@@ -383,7 +438,7 @@ extern "C" void l3d_steger_destroy(l3d_steger *h)
     if (!h) return;
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->taps, h->cells, h->cell_counts, h->in, h->out, h->counts};
+    void *bufs[] = {h->taps, h->cells, h->cell_counts, h->tile_list, h->in, h->out, h->counts};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -450,6 +505,8 @@ static int steger_create(double sigma, int brightness_threshold, int max_width, 
     alloc((void **)&h->taps, MAX_TAPS * sizeof(float));
     alloc((void **)&h->cells, B * h->max_cells * TW * sizeof(float2));
     alloc((void **)&h->cell_counts, B * h->max_cells * sizeof(int));
+    h->max_tiles = B * cdiv(max_width, TW) * cdiv(max_height, TH);
+    alloc((void **)&h->tile_list, (1 + 2 * h->max_tiles) * sizeof(int));
     alloc((void **)&h->in, B * (size_t)max_width * max_height * 3);
     alloc((void **)&h->out, B * (size_t)max_width * max_height * sizeof(float2));
     alloc((void **)&h->counts, B * sizeof(int));
@@ -486,12 +543,22 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
     const int R = a.R, HB = variant == VAR_FAST ? 1 : 2;
     const size_t lds = ((size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB + 2 * R) + (size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB) +
                         (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 3) * sizeof(float);
-    const dim3 grid(a.ntx, a.nty, B);
+    a.ntiles = a.ntx * a.nty * B;
+    // tiles with bright pixels -> list; cells of all other tiles are empty
+    L3D_REQUIRE((size_t)a.ntiles <= h->max_tiles, "steger: %d tiles exceed the handle's %zu", a.ntiles, h->max_tiles);
+    L3D_HIP_CHECK(hipMemsetAsync(h->tile_list, 0, (size_t)(1 + a.ntiles) * sizeof(int), s));
+    L3D_HIP_CHECK(hipMemsetAsync(h->tile_list + 1 + a.ntiles, 0xff, (size_t)a.ntiles * sizeof(int), s));   // list of -1
+    L3D_HIP_CHECK(hipMemsetAsync(h->cell_counts, 0, (size_t)B * a.rh * a.ntx * sizeof(int), s));
+    hipLaunchKernelGGL(k_steger_mark, dim3(cdiv(cdiv(a.rw, 4), 256), a.rh, B), dim3(256), 0, s, a, d_img, variant == VAR_HYBRID ? d_mask : nullptr,
+                       h->tile_list);
+    hipLaunchKernelGGL(k_steger_list, dim3(cdiv(a.ntiles, 256)), dim3(256), 0, s, a.ntiles, h->tile_list);
+    // the list's length stays on the device: a grid of a quarter of all tiles (at least 1024 blocks) walks it
+    const dim3 grid(std::min(a.ntiles, std::max(1024, a.ntiles / 4)));
     switch (variant) {
-    case VAR_FAST: hipLaunchKernelGGL(k_steger_tile<VAR_FAST>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
-    case VAR_IMPROVED: hipLaunchKernelGGL(k_steger_tile<VAR_IMPROVED>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
-    case VAR_PER_ROW: hipLaunchKernelGGL(k_steger_tile<VAR_PER_ROW>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
-    default: hipLaunchKernelGGL(k_steger_tile<VAR_HYBRID>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts); break;
+    case VAR_FAST: hipLaunchKernelGGL(k_steger_tile<VAR_FAST>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
+    case VAR_IMPROVED: hipLaunchKernelGGL(k_steger_tile<VAR_IMPROVED>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
+    case VAR_PER_ROW: hipLaunchKernelGGL(k_steger_tile<VAR_PER_ROW>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
+    default: hipLaunchKernelGGL(k_steger_tile<VAR_HYBRID>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
     }
     if (variant == VAR_PER_ROW || variant == VAR_HYBRID)
         hipLaunchKernelGGL(k_steger_rowbest, dim3(cdiv(B * a.rh, 256)), dim3(256), 0, s, B * a.rh, a.rh, a.ntx, h->cells, h->cell_counts);
