@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         const int gy = i / nb, bx = b0 + (i - gy * nb);
         const float *src = gt + gy * GW + bx;
         float s = 0.0f;
-        for (int k = 0; k < ks; k++) s = s + tp[k] * src[k];
+#pragma unroll 5
+        for (int k = 0; k < ks; k++) s = s + tp[k] * src[k];   // (unrolled: the LDS reads of five taps go out together)
         hrow[gy * BW + bx] = s;
     }
     __syncthreads();
@@ -225,6 +226,7 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         const int by = i / nb, bx = b0 + (i - by * nb);
         const float *src = hrow + (by + R) * BW + bx;
         float s = tp[R] * src[0];
+#pragma unroll 4
         for (int k = 1; k <= R; k++) s = s + tp[R + k] * (src[-k * BW] + src[k * BW]);
         bl[by * BW + bx] = s;
     }
