@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 64 for C3, 16 for C5)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--pipelines", type=int, default=1, help="independent pipelines (matcher + buffers + streams) the steps alternate between")
+    ap.add_argument("--separate-calls", action="store_true", help="gray, matcher and depth as three library calls instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -190,14 +191,19 @@ def main():
             p["side"].wait_stream(p["main"])
             with torch.cuda.stream(p["side"] if beside else p["main"]):
                 state["xy"], state["counts"] = p["steger"].extract_device(d_l, cap)
-            ops.bgr2gray_device(d_l, p["gl"])
-            ops.bgr2gray_device(d_r, p["gr"])
-            p["left"].compute_device(p["gl"], p["gr"], p["disp"])
-            d = p["disp"]
-            if use_wls:
-                p["right"].compute_device(p["gr"], p["gl"], p["dr"])
-                d = p["wls"].filter_device(p["disp"], p["gl"], p["dr"], p["df"])
-            ops.depth_from_disparity16_device(d, Q, p["depth"])
+            if use_wls or args.separate_calls:
+                ops.bgr2gray_device(d_l, p["gl"])
+                ops.bgr2gray_device(d_r, p["gr"])
+                p["left"].compute_device(p["gl"], p["gr"], p["disp"])
+                d = p["disp"]
+                if use_wls:
+                    p["right"].compute_device(p["gr"], p["gl"], p["dr"])
+                    d = p["wls"].filter_device(p["disp"], p["gl"], p["dr"], p["df"])
+                ops.depth_from_disparity16_device(d, Q, p["depth"])
+            else:
+                # gray of both views -> matcher -> depth in one library call: the reprojection of each half batch runs
+                # on the matcher's own streams beside the other half's kernels
+                p["left"].compute_depth_device(d_l, d_r, Q, p["disp"], p["depth"])
             p["main"].wait_stream(p["side"])
 
     def fence():

@@ -86,6 +86,15 @@ int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int
 int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch,
                             int16_t *d_disp, void *stream);
 
+/* The frame-pair step of the reference's get_frames / compute_depth in one call, device-resident
+ * (camera/single_usb_stereo_camera.py:319-346, readme.md:367): BGR -> gray of both views, the matcher, /16,
+ * reprojectImageTo3D Z and the validity masks.  d_left_bgr, d_right_bgr [batch][H][W][3]; d_depth [batch][H][W]
+ * float; d_disp [batch][H][W] int16 or NULL (the disparity then stays in the handle); Q16_host as for
+ * l3d_depth_from_disp16_device.  Equal to l3d_bgr2gray_device x2 + l3d_sgbm_compute_device +
+ * l3d_depth_from_disp16_device; the reprojection runs on the handle's two streams with its half of the batch. */
+int l3d_sgbm_compute_depth_device(l3d_sgbm *h, const uint8_t *d_left_bgr, const uint8_t *d_right_bgr, int batch,
+                                  const double *Q16_host, int16_t *d_disp, float *d_depth, void *stream);
+
 /* The tail of StereoSGBM::compute on its own: 3x3 median (replicated border) of
  * raw [batch][H][W] int16 disparity maps, then the speckle filter with the
  * handle's speckleWindowSize / speckleRange and newVal = 16*(minDisparity-1)

@@ -85,6 +85,7 @@ def _load():
         "l3d_sgbm_destroy": (None, [vp]),
         "l3d_sgbm_compute": (i, [vp, vp, vp, i, ss, ss, vp]),
         "l3d_sgbm_compute_device": (i, [vp, vp, vp, i, vp, vp]),
+        "l3d_sgbm_compute_depth_device": (i, [vp, vp, vp, i, vp, vp, vp, vp]),
         "l3d_sgbm_postfilter": (i, [vp, vp, i, vp]),
         "l3d_sgbm_fetch_stage": (i, [vp, i, vp, sz]),
         "l3d_sgbm_geometry": (i, [C.POINTER(SgbmParams), i, i, pi]),

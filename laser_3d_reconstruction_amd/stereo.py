@@ -131,6 +131,29 @@ class StereoSGBM:
         N.check(N.lib.l3d_sgbm_compute(hd, N.ptr(left), N.ptr(right), b, w, w * h, N.ptr(disp)), "l3d_sgbm_compute")
         return disp if batched else disp[0]
 
+    def compute_depth_device(self, left_bgr, right_bgr, Q=None, disp_out=None, depth_out=None):
+        """torch uint8 CUDA tensors (B,H,W,3) -> (int16 disparity, float32 depth) on the current stream: gray
+        conversion of both views, the matcher and the disparity -> depth step in one library call (the reference's
+        get_frames body, camera/single_usb_stereo_camera.py:319-346)."""
+        import torch
+
+        if left_bgr.dim() == 3:
+            left_bgr, right_bgr = left_bgr[None], right_bgr[None]
+        assert left_bgr.is_cuda and right_bgr.is_cuda and left_bgr.dtype == torch.uint8 and right_bgr.dtype == torch.uint8
+        assert left_bgr.is_contiguous() and right_bgr.is_contiguous() and left_bgr.shape == right_bgr.shape and left_bgr.shape[-1] == 3
+        b, h, w, _ = left_bgr.shape
+        hd = self._handle(w, h, b)
+        if disp_out is None:
+            disp_out = torch.empty((b, h, w), dtype=torch.int16, device=left_bgr.device)
+        if depth_out is None:
+            depth_out = torch.empty((b, h, w), dtype=torch.float32, device=left_bgr.device)
+        q = np.ascontiguousarray(Q, np.float64).reshape(16) if Q is not None else None
+        N.check(N.lib.l3d_sgbm_compute_depth_device(hd, C.c_void_p(left_bgr.data_ptr()), C.c_void_p(right_bgr.data_ptr()), b,
+                                                    N.ptr(q) if q is not None else None, C.c_void_p(disp_out.data_ptr()),
+                                                    C.c_void_p(depth_out.data_ptr()), _torch_stream_ptr(left_bgr)),
+                "l3d_sgbm_compute_depth_device")
+        return disp_out, depth_out
+
     def compute_device(self, left, right, out=None):
         """torch uint8 CUDA tensors (B,H,W) -> torch int16 CUDA tensor; enqueued on the current stream."""
         import torch

@@ -179,6 +179,35 @@ def test_sgbm_two_stream_halves_equal_whole_batch_and_oracle(gpu, O, monkeypatch
     assert np.array_equal(doubled.cpu().numpy(), split.astype(np.int32) * 2)
 
 
+def test_fused_depth_entry_point_equals_separate_calls(gpu, O):
+    """l3d_sgbm_compute_depth_device = gray of both views + matcher + disparity -> depth, for a batch that runs as two
+    halves and for a single pair, with and without a calibration."""
+    import torch
+    from laser_3d_reconstruction_amd import ops
+
+    W, H, D = 320, 180, 64
+    B = 9
+    frames = [_pair(W, H, D, 40 + k) for k in range(B)]
+    dev = torch.device("cuda", 0)
+    L = torch.from_numpy(np.stack([f[0] for f in frames])).to(dev)
+    R = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
+    Q = np.array([[1, 0, 0, -159.5], [0, 1, 0, -89.5], [0, 0, 0, 209.0], [0, 0, 15.94, 0]], np.float64)
+    m = _sgbm(**_ref_ctor(D, 5), max_batch=B)
+    for q in (Q, None):
+        for sl in (slice(0, B), slice(3, 4)):
+            disp, depth = m.compute_depth_device(L[sl].contiguous(), R[sl].contiguous(), q)
+            gl, gr = ops.bgr2gray_device(L[sl].contiguous()), ops.bgr2gray_device(R[sl].contiguous())
+            want_d = m.compute_device(gl, gr)
+            want_z = ops.depth_from_disparity16_device(want_d, q)
+            torch.cuda.synchronize()
+            assert torch.equal(disp, want_d) and torch.equal(depth, want_z)
+    # and against the oracle for one frame
+    gl0, gr0 = O.bgr2gray(frames[0][0]), O.bgr2gray(frames[0][1])
+    d0 = O.sgbm_compute(O.sgbm_params(**_ref_ctor(D, 5)), gl0, gr0)
+    disp, depth = m.compute_depth_device(L[:1].contiguous(), R[:1].contiguous(), Q)
+    assert np.array_equal(disp[0].cpu().numpy(), d0) and np.array_equal(depth[0].cpu().numpy(), O.depth_from_disp16(d0, Q))
+
+
 def test_sgbm_edge_cases(gpu, O):
     N = gpu
     # narrower than the disparity range: all invalid
