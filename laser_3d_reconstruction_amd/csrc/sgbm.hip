@@ -1015,11 +1015,15 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         asm volatile("" ::: "memory");
     };
     fetch2(A, nseg - 1);
-    for (int j = nseg - 1; j >= 0; j--) {
+    int j = nseg - 1;
+    for (; j >= 1; j -= 2) {
+        // two segments per turn with the buffers swapping roles: no copy of the segment in flight
         fetch2(B, j - 1);
         run2(A, j);
-        A = B;
+        fetch2(A, j - 2);
+        run2(B, j - 1);
     }
+    if (j == 0) run2(A, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
