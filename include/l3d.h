@@ -297,6 +297,20 @@ int l3d_reconstruct_from_depth(const double *uv, int n, const float *depth, int 
 int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv9, const double *plane4,
                           int refraction, double n_water, double *xyz, int device);
 
+/* The two calls above for laser pixels that are still in HBM, i.e. the device output of l3d_steger_extract_device
+ * (d_xy [batch][capacity][2] float32, d_counts [batch]) -- the frame loop of main.py:172-176 without a round trip
+ * through host memory.  Frame b back-projects through d_depth[b] ([batch][height][width] float32).  No compaction:
+ * d_xyz [batch][capacity][3] doubles, d_keep [batch][capacity] = 1 where the reference appends the point (slots
+ * past a frame's count: 0).  The float32 coordinates are widened to double first, which is what the reference's
+ * Python floats hold. */
+int l3d_reconstruct_from_depth_device(const float *d_xy, const int *d_counts, int capacity, int batch,
+                                      const float *d_depth, int width, int height, const double *K9, double *d_xyz,
+                                      int *d_keep, void *stream);
+/* d_xyz [batch][capacity][3] doubles: rows of NaN where the reference returns NaN and past a frame's count */
+int l3d_reconstruct_plane_device(const float *d_xy, const int *d_counts, int capacity, int batch,
+                                 const double *Kinv9, const double *plane4, int refraction, double n_water,
+                                 double *d_xyz, void *stream);
+
 /* replaces ImprovedLaserReconstructor.reconstruct_from_disparity (window_size = 0,
  * improved_reconstruction.py:37-86) and .reconstruct_with_interpolation (window_size odd >= 1:
  * median of the valid disparities of the window, :88-152).  uv: n (x, y) doubles; disparity

@@ -110,6 +110,7 @@ class FastStegerExtractor:
         self.verbose = verbose
         self._h = None
         self._cap = (0, 0, 0)
+        self._key = None
         if verbose:
             print(f"FastStegerExtractor: sigma={sigma} threshold={brightness_threshold} kernel={self.kernel_size}")
 
@@ -126,8 +127,11 @@ class FastStegerExtractor:
 
     def _handle(self, w, h, b):
         mw, mh, mb = self._cap
-        if self._h is None or w > mw or h > mh or b > mb:
+        key = (float(self.sigma), int(self.brightness_threshold))
+        # sigma / brightness_threshold are read on every call, as in the reference: a changed value rebuilds the handle
+        if self._h is None or w > mw or h > mh or b > mb or key != self._key:
             self._release()
+            self._key = key
             self._cap = (max(w, mw), max(h, mh), max(b, mb))
             hd = C.c_void_p()
             N.check(N.lib.l3d_steger_create(C.c_double(self.sigma), int(self.brightness_threshold), self._cap[0],

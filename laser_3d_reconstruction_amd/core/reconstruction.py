@@ -25,7 +25,9 @@ class Reconstructor:
 
     def reconstruct_point(self, u: float, v: float) -> np.ndarray:
         """3-D point of pixel (u, v) on the laser plane; [nan, nan, nan] when the ray is
-        parallel to the plane or the intersection lies behind the camera."""
+        parallel to the plane or the intersection lies behind the camera.  One kernel launch and one
+        round trip through host memory per call (tens of microseconds): use reconstruct_laser_line
+        for a list of pixels, as the reference's own frame loop does."""
         return ops.reconstruct_plane([[u, v]], self.K_inv, self.laser_plane, self.use_refraction,
                                      self.water_refraction_index, self.device)[0]
 
@@ -44,6 +46,49 @@ class Reconstructor:
             return np.array([])
         pts = ops.reconstruct_from_depth(laser_points, depth_image, self.K, self.device)
         return pts if len(pts) else np.array([])
+
+    # --- device-resident forms: the extractor's output stays in HBM (torch tensors on the current stream) ---
+    def reconstruct_from_depth_device(self, xy, counts, depth):
+        """xy (B,cap,2) float32, counts (B,) int32, depth (B,H,W) float32 CUDA tensors ->
+        (xyz (B,cap,3) float64, keep (B,cap) int32): row i of frame b is valid where keep is 1, i.e. where
+        reconstruct_from_depth would append the point."""
+        import ctypes as C
+        import torch
+        from .. import _native as N
+
+        assert xy.is_cuda and xy.dtype == torch.float32 and xy.is_contiguous() and xy.dim() == 3 and xy.shape[2] == 2
+        assert counts.dtype == torch.int32 and depth.dtype == torch.float32 and depth.is_contiguous() and depth.dim() == 3
+        b, cap, _ = xy.shape
+        assert depth.shape[0] == b and counts.shape[0] == b
+        h, w = depth.shape[1:]
+        xyz = torch.empty((b, cap, 3), dtype=torch.float64, device=xy.device)
+        keep = torch.empty((b, cap), dtype=torch.int32, device=xy.device)
+        k = np.ascontiguousarray(self.K, np.float64)
+        N.check(N.lib.l3d_reconstruct_from_depth_device(C.c_void_p(xy.data_ptr()), C.c_void_p(counts.data_ptr()), cap, b,
+                                                        C.c_void_p(depth.data_ptr()), w, h, N.ptr(k), C.c_void_p(xyz.data_ptr()),
+                                                        C.c_void_p(keep.data_ptr()),
+                                                        C.c_void_p(torch.cuda.current_stream(xy.device).cuda_stream)),
+                "l3d_reconstruct_from_depth_device")
+        return xyz, keep
+
+    def reconstruct_laser_line_device(self, xy, counts):
+        """xy (B,cap,2) float32, counts (B,) int32 CUDA tensors -> xyz (B,cap,3) float64: reconstruct_point of every
+        laser pixel (refraction as configured); rows of NaN where the reference drops the point."""
+        import ctypes as C
+        import torch
+        from .. import _native as N
+
+        assert xy.is_cuda and xy.dtype == torch.float32 and xy.is_contiguous() and xy.dim() == 3 and xy.shape[2] == 2
+        b, cap, _ = xy.shape
+        xyz = torch.empty((b, cap, 3), dtype=torch.float64, device=xy.device)
+        kinv = np.ascontiguousarray(self.K_inv, np.float64)
+        plane = np.ascontiguousarray(self.laser_plane, np.float64)
+        N.check(N.lib.l3d_reconstruct_plane_device(C.c_void_p(xy.data_ptr()), C.c_void_p(counts.data_ptr()), cap, b, N.ptr(kinv),
+                                                   N.ptr(plane), int(bool(self.use_refraction)), C.c_double(self.water_refraction_index),
+                                                   C.c_void_p(xyz.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(xy.device).cuda_stream)),
+                "l3d_reconstruct_plane_device")
+        return xyz
 
     def filter_outliers(self, points_3d: np.ndarray, threshold: float = 0.01) -> np.ndarray:
         """Keeps points whose distance to both sequence neighbours is below threshold

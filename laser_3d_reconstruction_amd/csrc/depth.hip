@@ -83,6 +83,22 @@ __global__ void __launch_bounds__(256) k_depth(const int16_t *__restrict__ disp1
     depth[i] = z;
 }
 
+// reconstruct_from_depth for one laser pixel (u, v): true and xyz[0..2] written where the reference appends a point
+__device__ __forceinline__ bool from_depth_px(double u, double v, const float *__restrict__ depth, int W, int H, double fx, double fy, double cx,
+                                              double cy, double *__restrict__ xyz)
+{
+    if (!(u == u && v == v && fabs(u) < 2147483000.0 && fabs(v) < 2147483000.0)) return false;
+    const long iu = (long)u, iv = (long)v; // truncation toward zero, as Python int()
+    if (!(0 <= iu && iu < W && 0 <= iv && iv < H)) return false;
+    const float dep = depth[(size_t)iv * W + iu];
+    if (!(dep > 0)) return false;
+    const double z = (double)dep / 1000.0;
+    xyz[0] = (u - cx) * z / fx;
+    xyz[1] = (v - cy) * z / fy;
+    xyz[2] = z;
+    return true;
+}
+
 // reconstruct_from_depth for n laser pixels: keep[i] = 1 and xyz[i] valid where the reference
 // appends a point.  Compaction (order preserving) happens on the host: n is a few thousand.
 __global__ void __launch_bounds__(256) k_from_depth(const double *__restrict__ uv, int n, const float *__restrict__ depth, int W, int H,
@@ -90,22 +106,22 @@ __global__ void __launch_bounds__(256) k_from_depth(const double *__restrict__ u
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double u = uv[2 * i], v = uv[2 * i + 1];
+    keep[i] = from_depth_px(uv[2 * i], uv[2 * i + 1], depth, W, H, fx, fy, cx, cy, xyz + 3 * (size_t)i) ? 1 : 0;
+}
+
+// The same for a batch of frames whose laser pixels are the extractor's device output: xy [B][cap][2] float32,
+// counts [B]; frame b back-projects through depth map b.  Slots past a frame's count get keep = 0.
+__global__ void __launch_bounds__(256) k_from_depth_batch(const float *__restrict__ xy, const int *__restrict__ counts, int cap,
+                                                          const float *__restrict__ depth, int W, int H, double fx, double fy, double cx, double cy,
+                                                          double *__restrict__ xyz, int *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= cap) return;
+    const size_t idx = (size_t)b * cap + i;
     int k = 0;
-    if (u == u && v == v && fabs(u) < 2147483000.0 && fabs(v) < 2147483000.0) {
-        const long iu = (long)u, iv = (long)v; // truncation toward zero, as Python int()
-        if (0 <= iu && iu < W && 0 <= iv && iv < H) {
-            const float dep = depth[(size_t)iv * W + iu];
-            if (dep > 0) {
-                const double z = (double)dep / 1000.0;
-                xyz[3 * i] = (u - cx) * z / fx;
-                xyz[3 * i + 1] = (v - cy) * z / fy;
-                xyz[3 * i + 2] = z;
-                k = 1;
-            }
-        }
-    }
-    keep[i] = k;
+    if (i < min(counts[b], cap))
+        k = from_depth_px((double)xy[2 * idx], (double)xy[2 * idx + 1], depth + (size_t)b * W * H, W, H, fx, fy, cx, cy, xyz + 3 * idx) ? 1 : 0;
+    keep[idx] = k;
 }
 
 // ImprovedLaserReconstructor (improved_reconstruction.py:17-186): triangulation straight from the disparity map.
@@ -212,11 +228,9 @@ struct PlaneArgs {
     int refraction;
 };
 
-__global__ void __launch_bounds__(256) k_plane(const double *__restrict__ uv, int n, PlaneArgs a, double *__restrict__ xyz)
+// reconstruct_point (+ _refraction_correction) for pixel (u, v): o[0..2] = the point, NaN where the reference returns NaN
+__device__ __forceinline__ void plane_px(double u, double v, const PlaneArgs &a, double *__restrict__ o)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double u = uv[2 * i], v = uv[2 * i + 1];
     double r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) r[k] = a.kinv[3 * k] * u + a.kinv[3 * k + 1] * v + a.kinv[3 * k + 2] * 1.0;
@@ -224,7 +238,6 @@ __global__ void __launch_bounds__(256) k_plane(const double *__restrict__ uv, in
     r[0] /= nr; r[1] /= nr; r[2] /= nr;
     const double pa = a.plane[0], pb = a.plane[1], pc = a.plane[2], pd = a.plane[3];
     const double den = pa * r[0] + pb * r[1] + pc * r[2];
-    double *o = xyz + 3 * (size_t)i;
     const double qnan = __builtin_nan("");
     if (fabs(den) < 1e-10) { o[0] = o[1] = o[2] = qnan; return; }
     const double t = -pd / den;
@@ -248,6 +261,25 @@ __global__ void __launch_bounds__(256) k_plane(const double *__restrict__ uv, in
         }
     }
     o[0] = P[0]; o[1] = P[1]; o[2] = P[2];
+}
+
+__global__ void __launch_bounds__(256) k_plane(const double *__restrict__ uv, int n, PlaneArgs a, double *__restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    plane_px(uv[2 * i], uv[2 * i + 1], a, xyz + 3 * (size_t)i);
+}
+
+// The same for the extractor's device output (see k_from_depth_batch); slots past a frame's count are filled with NaN
+__global__ void __launch_bounds__(256) k_plane_batch(const float *__restrict__ xy, const int *__restrict__ counts, int cap, PlaneArgs a,
+                                                     double *__restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= cap) return;
+    const size_t idx = (size_t)b * cap + i;
+    double *o = xyz + 3 * idx;
+    if (i < min(counts[b], cap)) plane_px((double)xy[2 * idx], (double)xy[2 * idx + 1], a, o);
+    else o[0] = o[1] = o[2] = __builtin_nan("");
 }
 
 static int check_device(int device, const char *who)
@@ -408,6 +440,34 @@ extern "C" int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv
     hipLaunchKernelGGL(k_plane, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double *)duv.p, n, a, (double *)dxyz.p);
     L3D_HIP_CHECK(hipGetLastError());
     L3D_HIP_CHECK(hipMemcpy(xyz, dxyz.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return L3D_OK;
+}
+
+extern "C" int l3d_reconstruct_from_depth_device(const float *d_xy, const int *d_counts, int capacity, int batch, const float *d_depth,
+                                                 int width, int height, const double *K9, double *d_xyz, int *d_keep, void *stream)
+{
+    L3D_REQUIRE(capacity >= 0 && batch >= 1 && width > 0 && height > 0, "l3d_reconstruct_from_depth_device: bad size");
+    if (capacity == 0) return L3D_OK;
+    L3D_REQUIRE(d_xy && d_counts && d_depth && K9 && d_xyz && d_keep, "l3d_reconstruct_from_depth_device: null argument");
+    hipLaunchKernelGGL(k_from_depth_batch, dim3(cdiv(capacity, 256), batch), dim3(256), 0, (hipStream_t)stream, d_xy, d_counts, capacity, d_depth,
+                       width, height, K9[0], K9[4], K9[2], K9[5], d_xyz, d_keep);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+extern "C" int l3d_reconstruct_plane_device(const float *d_xy, const int *d_counts, int capacity, int batch, const double *Kinv9,
+                                            const double *plane4, int refraction, double n_water, double *d_xyz, void *stream)
+{
+    L3D_REQUIRE(capacity >= 0 && batch >= 1, "l3d_reconstruct_plane_device: bad size");
+    if (capacity == 0) return L3D_OK;
+    L3D_REQUIRE(d_xy && d_counts && Kinv9 && plane4 && d_xyz, "l3d_reconstruct_plane_device: null argument");
+    PlaneArgs a;
+    for (int i = 0; i < 9; i++) a.kinv[i] = Kinv9[i];
+    for (int i = 0; i < 4; i++) a.plane[i] = plane4[i];
+    a.n_water = n_water;
+    a.refraction = refraction;
+    hipLaunchKernelGGL(k_plane_batch, dim3(cdiv(capacity, 256), batch), dim3(256), 0, (hipStream_t)stream, d_xy, d_counts, capacity, a, d_xyz);
+    L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;
 }
 

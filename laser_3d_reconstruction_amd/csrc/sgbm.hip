@@ -1571,7 +1571,17 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     L3D_REQUIRE(p && out, "l3d_sgbm_create: null argument");
     *out = nullptr;
     L3D_REQUIRE(width >= 3 && height >= 1 && max_batch >= 1, "l3d_sgbm_create: bad size %dx%d batch %d", width, height, max_batch);
-    L3D_REQUIRE(width <= 65535, "l3d_sgbm_create: width %d exceeds 65535", width);
+    if (width > 16384) {
+        // the left-right check keeps one 4-byte entry per image column in LDS (64 KiB without opting in to more)
+        set_error("l3d_sgbm_create: width %d exceeds 16384", width);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    if (p->speckleWindowSize > 0 && (unsigned long long)max_batch * (unsigned long long)width * (unsigned long long)height >= (1ull << 31)) {
+        // the speckle filter labels pixels with 32-bit indices over the whole batch
+        set_error("l3d_sgbm_create: %d frames of %dx%d exceed the 2^31 pixels the speckle filter can label; use a smaller max_batch",
+                  max_batch, width, height);
+        return L3D_ERR_UNSUPPORTED;
+    }
     if (p->mode != 2) {
         set_error("l3d_sgbm_create: only mode=2 (STEREO_SGBM_MODE_SGBM_3WAY) is built, got %d", p->mode);
         return L3D_ERR_UNSUPPORTED;

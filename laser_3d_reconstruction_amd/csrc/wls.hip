@@ -26,8 +26,16 @@ namespace l3d {
 
 constexpr int DT_W = 64, DT_H = 16; // discontinuity-map tile
 
-// var = box(d^2) - box(d)^2 over (2r+1)^2 with replicated borders of the sub-image,
-// conf = max(0, 1 - rolloff * var); box sums are exact integers.
+__device__ __forceinline__ int wls_reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// var = box(d^2) - box(d)^2 over (2r+1)^2, the sub-image extended by BORDER_REFLECT_101 (cv::boxFilter's default on the
+// float copy of the sub-image), conf = max(0, 1 - rolloff * var); box sums are exact integers, scaled by the double
+// 1 / (window area) and rounded to float once, as boxFilter's double accumulator does.
 __global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ disp, int W, int H, int x0, int rw, int r, float rolloff,
                                                   float *__restrict__ out)
 {
@@ -41,7 +49,7 @@ __global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ di
     const int16_t *d = disp + (size_t)b * W * H;
     for (int i = tid; i < GH * GW; i += 256) {
         const int gy = i / GW, gx = i - gy * GW;
-        const int x = min(max(tx0 - r + gx, 0), rw - 1), y = min(max(ty0 - r + gy, 0), H - 1);
+        const int x = wls_reflect101(tx0 - r + gx, rw), y = wls_reflect101(ty0 - r + gy, H);
         tile[i] = d[(size_t)y * W + x0 + x];
     }
     __syncthreads();
@@ -58,7 +66,7 @@ __global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ di
         h2[i] = q;
     }
     __syncthreads();
-    const int n = (2 * r + 1) * (2 * r + 1);
+    const double scale = 1.0 / ((2 * r + 1) * (2 * r + 1));
     for (int i = tid; i < DT_H * DT_W; i += 256) {
         const int ty = i / DT_W, x = i - ty * DT_W;
         if (tx0 + x >= rw || ty0 + ty >= H) continue;
@@ -67,8 +75,8 @@ __global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ di
             a += h1[(ty + j) * DT_W + x];
             q += h2[(ty + j) * DT_W + x];
         }
-        const float m1 = (float)((double)a / n);
-        const float m2 = (float)((double)q / n);
+        const float m1 = (float)((double)a * scale);
+        const float m2 = (float)((double)q * scale);
         const float var = m2 - m1 * m1;
         const float c = 1.0f - rolloff * var;
         out[((size_t)b * H + ty0 + ty) * rw + tx0 + x] = c > 0.0f ? c : 0.0f;

@@ -34,10 +34,16 @@ class _StegerHandle:
         self.h = None
         self.cap = (0, 0)
 
-    def get(self, w, h):
+    def get(self, w, h, args=None):
+        """`args` = the owner's current (sigma, threshold, response_threshold): the reference reads its attributes on
+        every call, so a changed value rebuilds the handle."""
         mw, mh = self.cap
-        if self.h is None or w > mw or h > mh:
+        if args is not None:
+            args = (float(args[0]), int(args[1]), float(args[2]))
+        if self.h is None or w > mw or h > mh or (args is not None and args != self.args):
             self.release()
+            if args is not None:
+                self.args = args
             self.cap = (max(w, mw), max(h, mh))
             hd = C.c_void_p()
             N.check(N.lib.l3d_steger_create_improved(C.c_double(self.args[0]), self.args[1], C.c_double(self.args[2]), self.cap[0],
@@ -73,7 +79,7 @@ class ImprovedStegerExtractor:
     def extract_points(self, image: np.ndarray, per_row: bool = False) -> np.ndarray:
         img, ch = _as_images(image)
         h, w = img.shape[:2]
-        hd = self._handle.get(w, h)
+        hd = self._handle.get(w, h, (self.sigma, self.brightness_threshold, self.response_threshold))
         cap = h if per_row else w * h
         xy = np.empty((cap, 2), np.float32)
         n = C.c_int(0)
@@ -130,7 +136,7 @@ class HybridLaserExtractor:
         if ch != 3:
             raise ValueError("HybridLaserExtractor expects a BGR image")
         h, w = img.shape[:2]
-        st = self._handle.get(w, h)
+        st = self._handle.get(w, h, (self.sigma, self.brightness_threshold, 0.5))
         mk = self._mask_maker(w, h)
         lo = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_lower).reshape(3)])
         hi = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_upper).reshape(3)])

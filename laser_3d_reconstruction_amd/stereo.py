@@ -201,6 +201,8 @@ class StereoSGBM:
         return out if batched else out[0]
 
     def fetch_stage(self, stage: int, batch: int, w: int, h: int) -> np.ndarray:
+        if self._h is None:
+            raise RuntimeError("fetch_stage() needs a compute call first (no handle yet)")
         g = self.geometry(w, h)
         if stage in (0, 1):
             arr = np.empty((batch, h, max(g["W1"], 0), self._p.numDisparities), np.int16)

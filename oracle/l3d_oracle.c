@@ -567,19 +567,21 @@ typedef struct {
 } orc_wls_params;
 
 /* depth-discontinuity confidence of one disparity sub-image (x in [x0,x0+rw)):
- *   var = box(d^2) - box(d)^2 over a (2r+1)^2 window, replicated borders of
- *   the sub-image; conf = max(0, 1 - rolloff * var).
- * Box sums are exact integers; means are rounded to float once. */
+ *   var = box(d^2) - box(d)^2 over a (2r+1)^2 window; conf = max(0, 1 - rolloff * var).
+ * The filter converts the sub-image to a float matrix of its own and calls cv::boxFilter with the
+ * default border, so the window is extended by BORDER_REFLECT_101 of the sub-image (not by the
+ * columns outside it).  boxFilter on float input accumulates in double (exact here: the values are
+ * integers) and scales by the double 1/(window area) before rounding to float once. */
 static void wls_disc_map(const int16_t *disp, int W, int H, int x0, int rw, int r, float rolloff, float *out /*H*rw*/)
 {
-    const int n = (2 * r + 1) * (2 * r + 1);
+    const double scale = 1.0 / ((2 * r + 1) * (2 * r + 1));
     int64_t *s1 = (int64_t *)malloc((size_t)H * rw * sizeof(int64_t));
     int64_t *s2 = (int64_t *)malloc((size_t)H * rw * sizeof(int64_t));
     for (int y = 0; y < H; y++)
         for (int x = 0; x < rw; x++) {
             int64_t a = 0, b = 0;
             for (int j = -r; j <= r; j++) {
-                int v = disp[(size_t)y * W + x0 + clampi(x + j, 0, rw - 1)];
+                int v = disp[(size_t)y * W + x0 + reflect101(x + j, rw)];
                 a += v; b += (int64_t)v * v;
             }
             s1[(size_t)y * rw + x] = a; s2[(size_t)y * rw + x] = b;
@@ -588,11 +590,11 @@ static void wls_disc_map(const int16_t *disp, int W, int H, int x0, int rw, int 
         for (int x = 0; x < rw; x++) {
             int64_t a = 0, b = 0;
             for (int j = -r; j <= r; j++) {
-                int yy = clampi(y + j, 0, H - 1);
+                int yy = reflect101(y + j, H);
                 a += s1[(size_t)yy * rw + x]; b += s2[(size_t)yy * rw + x];
             }
-            float m1 = (float)((double)a / n);
-            float m2 = (float)((double)b / n);
+            float m1 = (float)((double)a * scale);
+            float m2 = (float)((double)b * scale);
             float var = m2 - m1 * m1;
             float c = 1.0f - rolloff * var;
             out[(size_t)y * rw + x] = c > 0.0f ? c : 0.0f;

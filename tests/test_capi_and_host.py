@@ -322,3 +322,44 @@ def test_broadcast_and_sharding_over_gloo_world_size_2():
     for rank, Q, s, nd, mine, counts in res:
         assert Q == np.arange(16, dtype=np.float64).reshape(4, 4).tolist() and abs(s - want_sum) < 1e-6 and nd == 64
         assert mine == list(range(rank, 10, 2)) and counts == [5.0, 5.0]
+
+
+def test_bench_launcher_plumbing(monkeypatch):
+    """bench.py --gpus N starts N ranks itself (as a child process, before it touches the GPU) unless it already runs
+    under torch.distributed.run; the child gets the same arguments."""
+    import argparse
+    import bench
+
+    calls = []
+
+    def fake_run(cmd, env=None):
+        calls.append((cmd, env))
+        return 7
+
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "C4"]
+    ns = argparse.Namespace(gpus=4)
+    assert bench.spawn_ranks_if_needed(ns, argv, environ={"PATH": "/usr/bin"}, run=fake_run) == 7
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv):] == argv and os.path.basename(cmd[-len(argv) - 1]) == "bench.py"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # already a rank, or a single GPU: no child
+    assert bench.spawn_ranks_if_needed(ns, argv, environ={"WORLD_SIZE": "4"}, run=fake_run) is None
+    assert bench.spawn_ranks_if_needed(argparse.Namespace(gpus=1), argv, environ={}, run=fake_run) is None
+    assert len(calls) == 1
+    # the eight streams of configs[3] land on ranks round-robin, every stream exactly once
+    from laser_3d_reconstruction_amd import parallel
+    for world in (1, 2, 4, 8):
+        owned = [parallel.shard_indices(bench.C4_STREAMS, r, world) for r in range(world)]
+        assert sorted(s for o in owned for s in o) == list(range(8)) and all(len(o) == 8 // world for o in owned)
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
+    """The CPU leg of bench.py (the C restatement in the reference's frame-loop order, one thread and a forked pool)."""
+    import bench
+
+    r = bench.cpu_baseline(160, 64, 32, 5, False, 8000.0, 1.5, True, seconds_budget=0.05)
+    assert r["kind"] == "port" and r["value"] > 0 and r["one_thread"]["value"] > 0 and r["cores"] >= 1
+    r = bench.cpu_baseline(160, 64, 32, 5, True, 8000.0, 1.5, False, seconds_budget=0.05)
+    assert r["value"] > 0

@@ -904,3 +904,88 @@ def test_device_resident_entry_points_equal_host_entry_points(gpu, O):
         torch.cuda.synchronize()
         got = d_xyz.cpu().numpy()[d_keep.cpu().numpy() == 1]
         assert np.array_equal(got, O.triangulate_disparity(pts, disp.cpu().numpy(), Q, win))
+
+
+def test_device_resident_reconstruction_equals_host_entry_points_and_golden(gpu, O, golden):
+    """l3d_reconstruct_from_depth_device / l3d_reconstruct_plane_device on the Steger extractor's device output: per
+    frame the same points as the host entry points (which are pinned by the reference's golden vectors) and the oracle."""
+    import torch
+    from laser_3d_reconstruction_amd import FastStegerExtractor, Reconstructor
+
+    W, H, D = 320, 180, 32
+    dev = torch.device("cuda", 0)
+    frames = np.stack([_pair(W, H, D, 60 + k)[0] for k in range(3)])
+    frames[2] = 0                                                     # a frame without any laser pixel
+    L = torch.from_numpy(frames).to(dev)
+    rng = np.random.default_rng(9)
+    depth = rng.uniform(-50.0, 900.0, (3, H, W)).astype(np.float32)   # negative / zero depths are dropped
+    depth[0, ::7] = 0.0
+    d_depth = torch.from_numpy(depth).to(dev)
+    K = np.array(golden["K"])
+    cap = 2 * H
+    xy, cnt = FastStegerExtractor().extract_device(L, capacity=cap)
+    for refr in (True, False):
+        r = Reconstructor(K, np.array([0.05, -0.02, 1.0, -0.5]), use_refraction_correction=refr)
+        xyz, keep = r.reconstruct_from_depth_device(xy, cnt, d_depth)
+        pl = r.reconstruct_laser_line_device(xy, cnt)
+        torch.cuda.synchronize()
+        for b in range(3):
+            n = int(cnt[b].item())
+            assert (n == 0) == (b == 2) and n <= cap
+            pts = [(float(x), float(y)) for x, y in xy[b, :n].cpu().numpy()]
+            kp = keep[b].cpu().numpy().astype(bool)
+            assert not kp[n:].any()
+            got = xyz[b].cpu().numpy()[kp]
+            want = np.asarray(r.reconstruct_from_depth(pts, depth[b])).reshape(-1, 3)
+            assert np.array_equal(got, want)
+            if n:
+                assert np.array_equal(want, O.reconstruct_from_depth(np.array(pts), depth[b], K)) and 0 < len(want) < n
+            gp = pl[b].cpu().numpy()
+            assert np.isnan(gp[n:]).all()
+            line = np.asarray(r.reconstruct_laser_line(pts)).reshape(-1, 3)
+            assert np.array_equal(gp[:n][~np.isnan(gp[:n]).any(axis=1)], line)
+            if n:
+                assert np.array_equal(gp[:n], O.reconstruct_plane(np.array(pts), K, r.laser_plane, refr, 1.33))
+    # the golden plane cases through the device entry point: float32-representable pixel coordinates only
+    case = golden["plane_cases"][0]
+    uv = np.array(case["uv"], np.float64)
+    f32 = (uv.astype(np.float32).astype(np.float64) == uv).all(axis=1)
+    if f32.any():
+        r = Reconstructor(K, np.array(case["plane"], np.float64), use_refraction_correction=case["refraction"])
+        t_xy = torch.from_numpy(uv[f32].astype(np.float32)[None]).to(dev).contiguous()
+        t_n = torch.tensor([int(f32.sum())], dtype=torch.int32, device=dev)
+        got = r.reconstruct_laser_line_device(t_xy, t_n)[0].cpu().numpy()
+        want = np.array([[np.nan if c is None else c for c in p] for p in case["points"]])[f32]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=1e-12, atol=1e-14)
+
+
+def test_extractor_parameters_are_read_on_every_call(gpu, O):
+    """The reference reads self.sigma / self.brightness_threshold on every call (core/laser_extractor.py:192, 224):
+    changing the attribute between calls must take effect."""
+    from laser_3d_reconstruction_amd import FastStegerExtractor
+    from laser_3d_reconstruction_amd.improved_steger import ImprovedStegerExtractor
+
+    lb, _ = _pair(320, 180, 32, 5)
+    ex = FastStegerExtractor(3.0, 200)
+    a = ex.extract_points(lb)[0]
+    ex.sigma, ex.brightness_threshold = 1.5, 150
+    b = ex.extract_points(lb)[0]
+    want = O.steger_extract(lb, 1.5, 150)
+    assert len(b) == len(want) != len(a) and np.abs(b - want).max() <= 1e-3
+    im = ImprovedStegerExtractor(3.0, 200, 0.5)
+    a = im.extract_points(lb)
+    im.sigma, im.brightness_threshold, im.response_threshold = 2.0, 180, 0.3
+    b = im.extract_points(lb)
+    want = O.steger_improved(lb, 2.0, 180, 0.3, False)
+    assert len(b) == len(want) and (len(want) == 0 or np.abs(b - want).max() <= 1e-3)
+
+
+def test_sgbm_create_limits(gpu):
+    """Sizes the kernels cannot serve are refused at create time with a clear error, not at the first compute."""
+    import ctypes as C
+    N = gpu
+    p = N.SgbmParams(0, 16, 5, 600, 2400, 1, 63, 10, 100, 32, 2)
+    hd = C.c_void_p()
+    assert N.lib.l3d_sgbm_create(C.byref(p), 16400, 8, 1, 0, C.byref(hd)) == -2 and b"16384" in N.lib.l3d_last_error()
+    assert N.lib.l3d_sgbm_create(C.byref(p), 4096, 4096, 128, 0, C.byref(hd)) == -2 and b"speckle" in N.lib.l3d_last_error()
