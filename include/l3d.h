@@ -196,6 +196,18 @@ int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, int channels,
                               int batch, const int *roi, float *d_xy, int capacity, int *d_counts,
                               void *stream);
 
+/* l3d_steger_extract_device without a handle and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It calls no hipMalloc / hipFree or other allocating routine; the work buffers (tile list, per-cell
+ * counts and points, filter taps) live in one device array inside the library (8.6 MB per GPU, held until the process
+ * ends).  Limit: batch * height * ceil(width / 64) <= 16384 (for example one 1280x720 frame or four 640x360 frames);
+ * larger jobs are refused with L3D_ERR_CAPACITY.  Arguments and results as l3d_steger_extract_device, with sigma and
+ * brightness_threshold passed per call and `device` naming the GPU the pointers live on.  Every call on one GPU shares
+ * that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not. */
+int l3d_steger_extract_device_static(double sigma, int brightness_threshold, const uint8_t *d_img, int channels,
+                                     int width, int height, int batch, const int *roi, float *d_xy, int capacity,
+                                     int *d_counts, int device, void *stream);
+
 /* ---------------------------------------------------------------------------
  * HSV / brightness laser extractor (SimpleLaserExtractor,
  * core/laser_extractor.py:14-100).

@@ -106,6 +106,7 @@ def _load():
         "l3d_steger_destroy": (None, [vp]),
         "l3d_steger_extract": (i, [vp, vp, i, i, i, i, pi, vp, i, vp]),
         "l3d_steger_extract_device": (i, [vp, vp, i, i, i, i, pi, vp, i, vp, vp]),
+        "l3d_steger_extract_device_static": (i, [C.c_double, i, vp, i, i, i, i, pi, vp, i, vp, i, vp]),
         "l3d_simple_create": (i, [i, i, i, C.POINTER(vp)]),
         "l3d_simple_destroy": (None, [vp]),
         "l3d_simple_extract": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),

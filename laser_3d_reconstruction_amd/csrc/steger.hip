@@ -432,8 +432,28 @@ struct l3d_steger {
     uint8_t *in = nullptr;
     float2 *out = nullptr;
     int *counts = nullptr;
-    size_t max_cells = 0;
+    size_t max_cells = 0;        // cells of one image of the largest shape
+    size_t cells_capacity = 0;   // cells the `cells` / `cell_counts` arrays hold in all
 };
+
+// cv::GaussianBlur on a float image with ksize (0,0): ksize = round(sigma*4*2 + 1) | 1 taps of
+// cv::getGaussianKernel(ks, sigma, CV_32F): exp(-x^2 / 2 sigma^2) normalised in double.  Returns ks, or -ks when
+// it exceeds MAX_TAPS.
+static int steger_taps(double sigma, float *tf)
+{
+    const int ks = (int)std::nearbyint(sigma * 4 * 2 + 1) | 1;
+    if (ks > MAX_TAPS) return -ks;
+    double t[MAX_TAPS];
+    double sum = 0;
+    const double scale2x = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ks; i++) {
+        const double x = i - (ks - 1) * 0.5;
+        t[i] = std::exp(scale2x * x * x);
+        sum += t[i];
+    }
+    for (int i = 0; i < ks; i++) tf[i] = (float)(t[i] * (1.0 / sum));
+    return ks;
+}
 
 extern "C" void l3d_steger_destroy(l3d_steger *h)
 {
@@ -470,10 +490,10 @@ static int steger_create(double sigma, int brightness_threshold, int max_width, 
     L3D_REQUIRE(out, "l3d_steger_create: null argument");
     *out = nullptr;
     L3D_REQUIRE(sigma > 0 && max_width > 0 && max_height > 0 && max_batch > 0, "l3d_steger_create: bad argument");
-    // cv::GaussianBlur on a float image with ksize (0,0): ksize = round(sigma*4*2 + 1) | 1
-    const int ks = (int)std::nearbyint(sigma * 4 * 2 + 1) | 1;
-    if (ks > MAX_TAPS) {
-        set_error("l3d_steger_create: sigma %.3f needs a %d-tap kernel (max %d)", sigma, ks, MAX_TAPS);
+    float tf[MAX_TAPS];
+    const int ks = steger_taps(sigma, tf);
+    if (ks < 0) {
+        set_error("l3d_steger_create: sigma %.3f needs a %d-tap kernel (max %d)", sigma, -ks, MAX_TAPS);
         return L3D_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -486,20 +506,10 @@ static int steger_create(double sigma, int brightness_threshold, int max_width, 
     L3D_REQUIRE(h, "l3d_steger_create: out of host memory");
     h->device = device; h->max_w = max_width; h->max_h = max_height; h->max_batch = max_batch;
     h->sigma = sigma; h->thr = brightness_threshold; h->R = ks / 2;
-    // cv::getGaussianKernel(ks, sigma, CV_32F): exp(-x^2 / 2 sigma^2) normalised in double
-    std::vector<double> t(ks);
-    double sum = 0;
-    const double scale2x = -0.5 / (sigma * sigma);
-    for (int i = 0; i < ks; i++) {
-        const double x = i - (ks - 1) * 0.5;
-        t[i] = std::exp(scale2x * x * x);
-        sum += t[i];
-    }
-    std::vector<float> tf(ks);
-    for (int i = 0; i < ks; i++) tf[i] = (float)(t[i] * (1.0 / sum));
     DeviceGuard dg(device);
     const size_t B = (size_t)max_batch;
     h->max_cells = (size_t)max_height * cdiv(max_width, TW);
+    h->cells_capacity = B * h->max_cells;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     auto alloc = [&](void **ptr, size_t bytes) {
         if (e == hipSuccess) e = hipMalloc(ptr, bytes);
@@ -512,7 +522,7 @@ static int steger_create(double sigma, int brightness_threshold, int max_width, 
     alloc((void **)&h->in, B * (size_t)max_width * max_height * 3);
     alloc((void **)&h->out, B * (size_t)max_width * max_height * sizeof(float2));
     alloc((void **)&h->counts, B * sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(h->taps, tf.data(), ks * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->taps, tf, ks * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("l3d_steger_create: %s", hipGetErrorString(e));
         l3d_steger_destroy(h);
@@ -547,7 +557,9 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
                         (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 3) * sizeof(float);
     a.ntiles = a.ntx * a.nty * B;
     // tiles with bright pixels -> list; cells of all other tiles are empty
-    L3D_REQUIRE((size_t)a.ntiles <= h->max_tiles, "steger: %d tiles exceed the handle's %zu", a.ntiles, h->max_tiles);
+    L3D_REQUIRE((size_t)a.ntiles <= h->max_tiles, "steger: %d tiles exceed the %zu the work buffers hold", a.ntiles, h->max_tiles);
+    L3D_REQUIRE((size_t)B * a.rh * a.ntx <= h->cells_capacity, "steger: %zu cells exceed the %zu the work buffers hold", (size_t)B * a.rh * a.ntx,
+                h->cells_capacity);
     L3D_HIP_CHECK(hipMemsetAsync(h->tile_list, 0, (size_t)(1 + a.ntiles) * sizeof(int), s));
     L3D_HIP_CHECK(hipMemsetAsync(h->tile_list + 1 + a.ntiles, 0xff, (size_t)a.ntiles * sizeof(int), s));   // list of -1
     L3D_HIP_CHECK(hipMemsetAsync(h->cell_counts, 0, (size_t)B * a.rh * a.ntx * sizeof(int), s));
@@ -590,6 +602,98 @@ extern "C" int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, in
     L3D_REQUIRE(d_img && d_xy && d_counts, "l3d_steger_extract_device: null argument");
     DeviceGuard dg(h->device);
     return steger_run(h, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// l3d_steger_extract_device without any allocation: the work buffers live in a device array of the library
+// ---------------------------------------------------------------------------------------------
+namespace l3d {
+constexpr size_t kStaticCells = 16384;                                     // cells (one image row x 64 columns each)
+constexpr size_t kStaticTapsBytes = 512;                                   // MAX_TAPS floats, padded
+constexpr size_t kStaticListBytes = (1 + 2 * kStaticCells) * sizeof(int) + 252;   // tile flags + list (tiles <= cells), padded to 256
+constexpr size_t kStaticCountBytes = kStaticCells * sizeof(int);
+constexpr size_t kStaticCellBytes = kStaticCells * TW * sizeof(float2);
+constexpr size_t kStaticBytes = kStaticTapsBytes + kStaticListBytes + kStaticCountBytes + kStaticCellBytes;
+static_assert(kStaticListBytes % 256 == 0 && kStaticBytes % 256 == 0, "sub-buffers stay 256-byte aligned");
+// Every GPU the library runs on holds its own copy of this array (8.6 MB) until the process ends.  In host code the
+// name is only a handle for hipGetSymbolAddress: the per-device address it returns is what kernels and memsets get.
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kStaticBytes];
+
+struct TapsArg {
+    float t[MAX_TAPS];
+};
+__global__ void k_steger_put_taps(TapsArg v, int n, float *__restrict__ dst)
+{
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = v.t[i];
+}
+
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices];   // per device, set once (racing first calls store the same value)
+
+// address of this device's copy of `scratch`; `device` must be the current device
+static int static_scratch(int device, unsigned char **out)
+{
+    L3D_REQUIRE(device >= 0 && device < kMaxDevices, "static scratch: device %d out of range", device);
+    unsigned char *p = __atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE);
+    if (!p) {
+        void *sym = nullptr;
+        L3D_HIP_CHECK(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+        L3D_REQUIRE(sym && ((uintptr_t)sym & 255) == 0, "static scratch: hipGetSymbolAddress returned %p", sym);
+        p = (unsigned char *)sym;
+        __atomic_store_n(&g_scratch_ptr[device], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return L3D_OK;
+}
+} // namespace l3d
+
+extern "C" int l3d_steger_extract_device_static(double sigma, int brightness_threshold, const uint8_t *d_img, int channels, int width,
+                                                int height, int batch, const int *roi, float *d_xy, int capacity, int *d_counts, int device,
+                                                void *stream)
+{
+    const char *who = "l3d_steger_extract_device_static";
+    L3D_REQUIRE(d_img && d_xy && d_counts, "%s: null argument", who);
+    L3D_REQUIRE(channels == 1 || channels == 3, "%s: channels must be 1 or 3, got %d", who, channels);
+    L3D_REQUIRE(sigma > 0 && width > 0 && height > 0 && batch >= 1 && capacity >= 0, "%s: bad argument", who);
+    // the whole image must fit even when a region of interest makes the job smaller: one rule, easy to state
+    const size_t cells = (size_t)batch * height * cdiv(width, TW);
+    if (cells > kStaticCells) {
+        set_error("%s: %d image(s) of %dx%d need %zu cells (rows x 64-column tiles); the static work buffer holds %zu "
+                  "(e.g. one 1280x720 frame or four 640x360 frames) -- use l3d_steger_extract_device with a handle for more",
+                  who, batch, width, height, cells, kStaticCells);
+        return L3D_ERR_CAPACITY;
+    }
+    TapsArg taps;
+    const int ks = steger_taps(sigma, taps.t);
+    if (ks < 0) {
+        set_error("%s: sigma %.3f needs a %d-tap kernel (max %d)", who, sigma, -ks, MAX_TAPS);
+        return L3D_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("%s: no HIP device available", who);
+        return L3D_ERR_NO_DEVICE;
+    }
+    L3D_REQUIRE(device >= 0 && device < ndev, "%s: device %d out of range (%d devices)", who, device, ndev);
+    DeviceGuard dg(device);
+    unsigned char *base = nullptr;
+    int rc = static_scratch(device, &base);
+    if (rc) return rc;
+    // a handle-shaped view of the static array (nothing in it is owned)
+    l3d_steger v;
+    v.device = device; v.max_w = width; v.max_h = height; v.max_batch = batch;
+    v.sigma = sigma; v.thr = brightness_threshold; v.R = ks / 2;
+    v.taps = reinterpret_cast<float *>(base);
+    v.tile_list = reinterpret_cast<int *>(base + kStaticTapsBytes);
+    v.cell_counts = reinterpret_cast<int *>(base + kStaticTapsBytes + kStaticListBytes);
+    v.cells = reinterpret_cast<float2 *>(base + kStaticTapsBytes + kStaticListBytes + kStaticCountBytes);
+    v.max_tiles = kStaticCells;
+    v.max_cells = (size_t)height * cdiv(width, TW);
+    v.cells_capacity = kStaticCells;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_steger_put_taps, dim3(1), dim3(MAX_TAPS < 64 ? 64 : 128), 0, s, taps, ks, v.taps);
+    return steger_run(&v, d_img, channels, width, height, batch, roi, d_xy, capacity, d_counts, s);
 }
 
 // host images in, points out, through the handle's staging buffers
