@@ -116,6 +116,15 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
     if (LPP >= 16) v = min(v, dpp_row<DPP_ROW_MIRROR>(0xffffffffu, v));
     return v;
 }
+template <int LPP>
+__device__ __forceinline__ int group_min_i32(int v)
+{
+    v = min(v, (int)dpp_row<DPP_QUAD_XOR1>(0x7fffffffu, (uint32_t)v));
+    v = min(v, (int)dpp_row<DPP_QUAD_XOR2>(0x7fffffffu, (uint32_t)v));
+    if (LPP >= 8) v = min(v, (int)dpp_row<DPP_ROW_HALF_MIRROR>(0x7fffffffu, (uint32_t)v));
+    if (LPP >= 16) v = min(v, (int)dpp_row<DPP_ROW_MIRROR>(0x7fffffffu, (uint32_t)v));
+    return v;
+}
 // Minimum over both int16 halves of `v` and over the lanes of the group, returned in both
 // halves of the result.  A word with two equal halves orders as int32 exactly like its halves
 // order as int16, and 32-bit v_min_i32 can carry a DPP modifier (packed 16-bit ops cannot).
@@ -224,13 +233,14 @@ struct PadFlags {
     __device__ __forceinline__ uint32_t initial(int p) const { return (PAD && on[p]) ? 0x7fff7fffu : 0u; }
 };
 
-template <int NP, int LPP, bool PAD>
+// BIGP2 = false: the caller knows that P2 <= 32767 (one addition applies it).
+template <int NP, int LPP, bool PAD, bool BIGP2 = true>
 __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (&st)[NP], uint32_t prevMin, const SgmPenalty &k, bool first,
                                              bool last, const PadFlags<NP, PAD> &pad)
 {
     const uint32_t BIG = 0x7fff7fffu;
     uint32_t mp2v = pk_adds(prevMin, k.P2a);
-    if (k.P2b) {
+    if (BIGP2 && k.P2b) {
         // kernel-uniform and rare (P2 > 32767): the empty statement keeps this a branch instead of two
         // additions and a select on every step
         asm volatile("" ::: "memory");
@@ -715,15 +725,18 @@ __device__ __forceinline__ void uniq_window_fill(uint32_t *window, int tid, int 
 template <int NP, int LPP>
 __device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, const uint32_t *window)
 {
-    uint32_t key = 0xffffffffu;
+    // per disparity a signed 32-bit key (S << 16 | d): ordering by S, then by d (the first minimum wins); the
+    // disparities of a word sit side by side in dpair[p], so each key is one byte permute
+    int skey = 0x7fffffff;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        const uint32_t sb = S[p] ^ 0x80008000u; // both halves biased by 32768
-        const uint32_t k0 = (sb << 16) | (uint32_t)(d0 + 2 * p);
-        const uint32_t k1 = (sb & 0xffff0000u) | (uint32_t)(d0 + 2 * p + 1);
-        key = min(key, min(k0, k1));
+        const uint32_t dpair = (uint32_t)(d0 + 2 * p) * 0x10001u + 0x10000u;
+        const int k0 = (int)__builtin_amdgcn_perm(S[p], dpair, 0x05040100u);   // S low half  : disparity d0 + 2p
+        const int k1 = (int)__builtin_amdgcn_perm(S[p], dpair, 0x07060302u);   // S high half : disparity d0 + 2p + 1
+        skey = min(skey, min(k0, k1));
     }
-    key = group_min_u32<LPP>(key);
+    skey = group_min_i32<LPP>(skey);
+    const uint32_t key = (uint32_t)skey ^ 0x80000000u;   // cost biased by 32768: the unsigned form the later stages order by
     if (g.uniq <= 0) return key;
     const int best = (int)(key & 0xffffu);
     const int minS = (int)(key >> 16) - 32768;
@@ -933,7 +946,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                         for (int p = 0; p < NP; p++) o.v[p] = st[p];
                         if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)(x / SEG) * (uint32_t)col_bytes);
                     }
-                    mn = sgm_step<NP, LPP, PAD>(cost(ring[u]), st, mn, pen, first, last, pad);
+                    mn = sgm_step<NP, LPP, PAD, !TONLY>(cost(ring[u]), st, mn, pen, first, last, pad);
                 }
                 ring[u] = fetch(x + RING);
             }
@@ -963,7 +976,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP, PAD>(cost(s.c[u]), fst, fmn, pen, first, last, pad);
+            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP, PAD, !TONLY>(cost(s.c[u]), fst, fmn, pen, first, last, pad);
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
         }
@@ -974,7 +987,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 // (TONLY: cost() already ran on this column in the loop above and left C in place)
                 const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
                 const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
-                rmn = sgm_step<NP, LPP, PAD>(cu, rst, rmn, pen, first, last, pad);
+                rmn = sgm_step<NP, LPP, PAD, !TONLY>(cu, rst, rmn, pen, first, last, pad);
                 Pack<NP> S;
 #pragma unroll
                 for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);

@@ -106,6 +106,22 @@ def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     assert (got[:, :max(mind + D, 0)] == (mind - 1) * 16).all()
 
 
+@pytest.mark.parametrize("W,H,D,b", [(640, 360, 64, 5), (400, 200, 96, 9), (200, 64, 32, 7), (240, 160, 64, 15)])
+def test_sgbm_every_stage_bit_exact_batch_handle(gpu, O, W, H, D, b):
+    """A handle for batches (max_batch > 4) runs other kernel variants than a single-frame handle (8 lanes per pixel
+    up to 96 disparities instead of 16): the same stage-by-stage check on those."""
+    kw = _ref_ctor(D, b)
+    lb, rb = _pair(W, H, D, 13)
+    gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+    m = _sgbm(**kw, max_batch=5)
+    got = m.compute(gl, gr)
+    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), gl, gr)
+    assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C), "aggregated cost volume"
+    assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.T), "top-down path volume"
+    assert np.array_equal(m.fetch_stage(2, 1, W, H)[0], dbg.raw), "disparity before median"
+    assert np.array_equal(got, dbg.disp), "final disparity"
+
+
 def test_sgbm_two_volume_path_bit_exact(gpu, O, monkeypatch):
     """The matcher normally stores the path volume only and rebuilds the aggregated cost; the layout with both volumes
     (used when a cost could saturate) is forced here on the headline configuration."""
