@@ -90,8 +90,9 @@ int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d
  * (camera/single_usb_stereo_camera.py:319-346, readme.md:367): BGR -> gray of both views, the matcher, /16,
  * reprojectImageTo3D Z and the validity masks.  d_left_bgr, d_right_bgr [batch][H][W][3]; d_depth [batch][H][W]
  * float; d_disp [batch][H][W] int16 or NULL (the disparity then stays in the handle); Q16_host as for
- * l3d_depth_from_disp16_device.  Equal to l3d_bgr2gray_device x2 + l3d_sgbm_compute_device +
- * l3d_depth_from_disp16_device; the reprojection runs on the handle's two streams with its half of the batch. */
+ * l3d_depth_from_disp16_device.  Results equal l3d_bgr2gray_device x2 + l3d_sgbm_compute_device +
+ * l3d_depth_from_disp16_device; here the matcher's first kernel converts the colour frames on the way in (no gray
+ * plane is written) and the reprojection runs on the handle's two streams with its half of the batch. */
 int l3d_sgbm_compute_depth_device(l3d_sgbm *h, const uint8_t *d_left_bgr, const uint8_t *d_right_bgr, int batch,
                                   const double *Q16_host, int16_t *d_disp, float *d_depth, void *stream);
 

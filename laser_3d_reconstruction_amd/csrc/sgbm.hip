@@ -276,18 +276,6 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (
 // ---------------------------------------------------------------------------------------------
 // K1: x-Sobel prefilter + Birchfield-Tomasi half-pixel min/max for both images
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void prefilter_px(const uint8_t *img, int W, int H, int y, int x, int ftzero, int &grad, int &raw)
-{
-    if (x <= 0 || x >= W - 1) { grad = ftzero; raw = ftzero; return; }
-    const uint8_t *r0 = img + (size_t)y * W;
-    const uint8_t *rn = y > 0 ? r0 - W : r0;
-    const uint8_t *rs = y < H - 1 ? r0 + W : r0;
-    int s = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + (int)rn[x + 1] - (int)rn[x - 1] + (int)rs[x + 1] - (int)rs[x - 1];
-    s = s < -ftzero ? -ftzero : (s > ftzero ? ftzero : s);
-    grad = s + ftzero;
-    raw = r0[x];
-}
-
 // The six per-pixel quantities of one image at (x, y) from the prefiltered values of x-1, x, x+1
 struct PixRec {
     int gc, glo, ghi, rc, rlo, rhi;
@@ -302,62 +290,101 @@ __device__ __forceinline__ PixRec pix_rec(int x, int W, int gm, int gc, int gp, 
     return o;
 }
 
-// One thread per 4 consecutive pixels of a row, both images.  Away from the image's left and right edge the
-// three rows are read as whole words and the results leave as two 16-byte stores (left records) and one
-// 4-byte store per right-image plane; the edge groups take the per-pixel path.
+// One wave per strip of PF_ROWS image rows x 62 groups of 4 pixels of one image (blockIdx.z = 2 * frame + side); a
+// lane owns one group of 4 consecutive pixels and walks down the strip with a window of three rows in registers.
+// CH = 1: gray input; CH = 3: BGR input, converted on the way in with the fixed-point weights of
+// cv2.cvtColor(BGR2GRAY) (camera/single_usb_stereo_camera.py:320-321), so the fused depth entry point reads each
+// colour frame once and never writes a gray plane.  Per row a lane loads its own four pixels as whole words (12 bytes
+// of BGR), takes the gray words of the groups left and right of it from its neighbour lanes (lanes 0 and 63 only
+// supply those), computes the clipped x-Sobel value of six pixels and the six quantities of its four, and stores them
+// as two 16-byte stores (left records) or one 4-byte store per plane, mirrored in x (right image).
+// No LDS and no barrier on purpose: the kernel runs beside the other half batch's scan kernels, whose blocks leave
+// less than 1 KB of a CU's LDS free -- a tiled variant with 1.4 KB of LDS per block was faster alone and made the whole
+// step 4 % slower, because its blocks could only start where a block of the vertical kernel had left for good.
+constexpr int PF_ROWS = 8, PF_GROUPS = 62;
+
+template <int CH>
 __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right,
                                                    int W, int H, int ftzero, uint2 *__restrict__ lrec, uint8_t *__restrict__ rrev)
 {
-    // groups of 4 pixels are numbered through the whole image so that no lane idles at the end of a row
-    const int ngx = (W + 3) / 4;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = gid / ngx, x0 = (gid - y * ngx) * 4, b = blockIdx.z;
-    if (y >= H) return;
-    const size_t img_off = (size_t)b * W * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ngx = (W + 3) / 4, nwx = (ngx + PF_GROUPS - 1) / PF_GROUPS;
+    const int wid = blockIdx.x * 4 + wave;                  // wave index over (row strip, strip of groups)
+    const int sy = wid / nwx, sx = wid - sy * nwx;
+    const int ys = sy * PF_ROWS;
+    if (ys >= H) return;                                    // whole wave
+    const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int gq = sx * PF_GROUPS + lane - 1, xq = gq * 4;  // this lane's group and its first pixel
     const size_t plane = (size_t)W * H;
-    const bool fast = x0 >= 4 && x0 + 8 <= W;
-    for (int side = 0; side < 2; side++) {
-        const uint8_t *img = (side == 0 ? left : right) + img_off;
-        PixRec rec[4];
-        if (fast) {
-            // bytes x0-4 .. x0+7 of the three rows; every pixel x0-1 .. x0+4 is an interior column
-            const uint8_t *r0 = img + (size_t)y * W, *rn = y > 0 ? r0 - W : r0, *rs = y < H - 1 ? r0 + W : r0;
-            uint32_t w0[3], wn[3], ws[3];
-            __builtin_memcpy(w0, r0 + x0 - 4, 12);
-            __builtin_memcpy(wn, rn + x0 - 4, 12);
-            __builtin_memcpy(ws, rs + x0 - 4, 12);
-            auto byte = [](const uint32_t (&w)[3], int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu); };
-            int g[6], r[6];
+    const uint8_t *img = (side == 0 ? left : right) + (size_t)b * plane * CH;
+    const bool have = gq >= 0 && xq < W;                    // the group holds image pixels
+    const bool whole = have && xq + 4 <= W;
+    const bool owner = have && lane >= 1 && lane <= PF_GROUPS;
+    // gray values of this lane's four pixels in image row y (clamped: the Sobel kernel replicates the first / last row)
+    auto gray_word = [&](int y) -> uint32_t {
+        const uint8_t *row = img + (size_t)min(max(y, 0), H - 1) * W * CH;
+        uint32_t v = 0;
+        if (whole) {
+            if (CH == 3) {
+                uint32_t w[3];
+                __builtin_memcpy(w, row + (size_t)xq * 3, 12);
+                const uint32_t p0 = ((w[0] >> 16 & 0xffu) * 9798u + (w[0] >> 8 & 0xffu) * 19235u + (w[0] & 0xffu) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p1 = ((w[1] >> 8 & 0xffu) * 9798u + (w[1] & 0xffu) * 19235u + (w[0] >> 24) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p2 = ((w[2] & 0xffu) * 9798u + (w[1] >> 24) * 19235u + (w[1] >> 16 & 0xffu) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p3 = ((w[2] >> 24) * 9798u + (w[2] >> 16 & 0xffu) * 19235u + (w[2] >> 8 & 0xffu) * 3735u + (1u << 14)) >> 15;
+                v = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+            } else
+                __builtin_memcpy(&v, row + xq, 4);
+        } else if (have) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) { // pixel x0 - 1 + k sits at byte k + 3
-                int v = (byte(w0, k + 4) - byte(w0, k + 2)) * 2 + byte(wn, k + 4) - byte(wn, k + 2) + byte(ws, k + 4) - byte(ws, k + 2);
-                v = v < -ftzero ? -ftzero : (v > ftzero ? ftzero : v);
-                g[k] = v + ftzero;
-                r[k] = byte(w0, k + 3);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) rec[i] = pix_rec(x0 + i, W, g[i], g[i + 1], g[i + 2], r[i], r[i + 1], r[i + 2]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int x = min(x0 + i, W - 1);
-                int gm, rm, gc, rc, gp, rp;
-                prefilter_px(img, W, H, y, x, ftzero, gc, rc);
-                if (x > 0) prefilter_px(img, W, H, y, x - 1, ftzero, gm, rm); else { gm = gc; rm = rc; }
-                if (x < W - 1) prefilter_px(img, W, H, y, x + 1, ftzero, gp, rp); else { gp = gc; rp = rc; }
-                rec[i] = pix_rec(x, W, gm, gc, gp, rm, rc, rp);
+            for (int k = 0; k < 4; k++) {                   // the image's last, partial group: pixel by pixel (pixels past the edge are never used)
+                const uint8_t *px = row + (size_t)min(xq + k, W - 1) * CH;
+                const uint32_t q = CH == 3 ? ((uint32_t)px[2] * 9798u + (uint32_t)px[1] * 19235u + (uint32_t)px[0] * 3735u + (1u << 14)) >> 15 : px[0];
+                v |= q << (8 * k);
             }
         }
+        return v;
+    };
+    // window of three rows: [row][0..2] = gray words of the groups gq-1, gq, gq+1
+    uint32_t wn[3], w0[3], ws[3];
+    auto fill = [&](uint32_t (&w)[3], int y) __attribute__((always_inline)) {
+        w[1] = gray_word(y);
+        w[0] = __shfl_up(w[1], 1);
+        w[2] = __shfl_down(w[1], 1);
+    };
+    fill(w0, ys - 1);
+    fill(ws, ys);
+    const size_t img_off = (size_t)b * plane;
+    const int yend = min(ys + PF_ROWS, H);
+    for (int y = ys; y < yend; y++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { wn[k] = w0[k]; w0[k] = ws[k]; }
+        fill(ws, y + 1);
+        if (!owner) continue;
+        auto byte = [](const uint32_t (&w)[3], int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+        int g[6], rw[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {     // pixel xq - 1 + k sits at byte k + 3
+            const int x = xq - 1 + k;
+            int v = (byte(w0, k + 4) - byte(w0, k + 2)) * 2 + byte(wn, k + 4) - byte(wn, k + 2) + byte(ws, k + 4) - byte(ws, k + 2);
+            v = min(max(v, -ftzero), ftzero) + ftzero;
+            const bool border = x <= 0 || x >= W - 1;   // image columns 0 and W-1 (and beyond): both channels read ftzero
+            g[k] = border ? ftzero : v;
+            rw[k] = border ? ftzero : byte(w0, k + 3);
+        }
+        PixRec rec[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) rec[i] = pix_rec(min(xq + i, W - 1), W, g[i], g[i + 1], g[i + 2], rw[i], rw[i + 1], rw[i + 2]);
         if (side == 0) {
-            uint2 *o = lrec + img_off + (size_t)y * W + x0;
+            uint2 *o = lrec + img_off + (size_t)y * W + xq;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (x0 + i < W)
+                if (xq + i < W)
                     o[i] = make_uint2((uint32_t)(rec[i].gc | (rec[i].glo << 8) | (rec[i].ghi << 16)), (uint32_t)(rec[i].rc | (rec[i].rlo << 8) | (rec[i].rhi << 16)));
         } else {
-            // mirrored in x: pixels x0 .. x0+3 land on bytes W-1-x0 down to W-4-x0
-            uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - x0);
-            if (x0 + 4 <= W) {
+            // mirrored in x: pixels xq .. xq+3 land on bytes W-1-xq down to W-4-xq
+            uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - xq);
+            if (xq + 4 <= W) {
                 const uint32_t q[6] = {
                     (uint32_t)(rec[3].gc | (rec[2].gc << 8) | (rec[1].gc << 16) | (rec[0].gc << 24)),
                     (uint32_t)(rec[3].glo | (rec[2].glo << 8) | (rec[1].glo << 16) | (rec[0].glo << 24)),
@@ -370,7 +397,7 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (x0 + i < W) {
+                    if (xq + i < W) {
                         uint8_t *oi = o - i;
                         oi[0] = (uint8_t)rec[i].gc; oi[plane] = (uint8_t)rec[i].glo; oi[2 * plane] = (uint8_t)rec[i].ghi;
                         oi[3 * plane] = (uint8_t)rec[i].rc; oi[4 * plane] = (uint8_t)rec[i].rlo; oi[5 * plane] = (uint8_t)rec[i].rhi;
@@ -1790,12 +1817,17 @@ static l3d_sgbm sgbm_view(const l3d_sgbm *h, int f0, int part)
 }
 
 // prefilter ... speckle filter of B frames on stream s; `stamp` marks the kernel boundaries for the per-kernel timing
+// (channels = 3: the inputs are BGR frames, converted to gray inside the prefilter)
 template <typename Stamp>
-static int sgbm_run_part(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
+static int sgbm_run_part(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int channels, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
 {
     const SgbmGeom &g = h->g;
     stamp();
-    hipLaunchKernelGGL(k_prefilter, dim3(cdiv(cdiv(g.W, 4) * g.H, 256), 1, B), dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
+    const dim3 gp(cdiv(cdiv(g.H, PF_ROWS) * cdiv(cdiv(g.W, 4), PF_GROUPS), 4), 1, 2 * B);   // four waves (strips) per block
+    if (channels == 3)
+        hipLaunchKernelGGL(k_prefilter<3>, gp, dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
+    else
+        hipLaunchKernelGGL(k_prefilter<1>, gp, dim3(256), 0, s, d_left, d_right, g.W, g.H, g.ftzero, h->lrec, h->rrev);
     stamp();
     const bool have_v = dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
     stamp();
@@ -1821,8 +1853,8 @@ constexpr int kSplitMinBatch = 8;
 // f0 .. f0+nb-1 on the stream that part runs on (the fused depth entry point converts to gray before and reprojects
 // after, so that these stages of one half overlap the other half's scan kernels too); they return a status.
 template <typename Before, typename After>
-static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s, Before &&before,
-                    After &&after)
+static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int channels, int B, int16_t *d_disp, hipStream_t s,
+                    Before &&before, After &&after)
 {
     const SgbmGeom &g = h->g;
     const size_t px = (size_t)g.W * g.H;
@@ -1849,7 +1881,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
             const int nb = (B * (c + 1)) / nchunk - (B * c) / nchunk;
             l3d_sgbm v = sgbm_view(h, f0, c);
             rc = before(f0, nb, h->sub[c & 1]);
-            if (rc == L3D_OK) rc = sgbm_run_part(&v, d_left + f0 * px, d_right + f0 * px, nb, d_disp + f0 * px, h->sub[c & 1], no_stamp);
+            if (rc == L3D_OK) rc = sgbm_run_part(&v, d_left + f0 * px * channels, d_right + f0 * px * channels, channels, nb, d_disp + f0 * px, h->sub[c & 1], no_stamp);
             if (rc == L3D_OK) rc = after(f0, nb, h->sub[c & 1]);
             f0 += nb;
         }
@@ -1875,7 +1907,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
         if (slot >= 0) (void)hipEventRecord(h->ev[slot][mark++], s);
     };
     int rc = before(0, B, s);
-    if (rc == L3D_OK) rc = sgbm_run_part(h, d_left, d_right, B, d_disp, s, stamp);
+    if (rc == L3D_OK) rc = sgbm_run_part(h, d_left, d_right, channels, B, d_disp, s, stamp);
     if (rc == L3D_OK) rc = after(0, B, s);
     if (rc) return rc;
     L3D_HIP_CHECK(hipGetLastError());
@@ -1885,7 +1917,7 @@ static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, 
 static int sgbm_run(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int B, int16_t *d_disp, hipStream_t s)
 {
     auto nothing = [](int, int, hipStream_t) { return (int)L3D_OK; };
-    return sgbm_run(h, d_left, d_right, B, d_disp, s, nothing, nothing);
+    return sgbm_run(h, d_left, d_right, 1, B, d_disp, s, nothing, nothing);
 }
 
 extern "C" int l3d_sgbm_compute_device(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_right, int batch, int16_t *d_disp, void *stream)
@@ -1906,26 +1938,19 @@ extern "C" int l3d_sgbm_compute_depth_device(l3d_sgbm *h, const uint8_t *d_left_
     const SgbmGeom &g = h->g;
     const size_t px = (size_t)g.W * g.H;
     int16_t *disp = d_disp ? d_disp : h->out_disp;
-    auto gray = [&](int f0, int nb, hipStream_t st) {
-        int rc = l3d_bgr2gray_device(d_left_bgr + f0 * px * 3, g.W, g.H, nb, h->in_left + f0 * px, h->device, st);
-        if (rc == L3D_OK) rc = l3d_bgr2gray_device(d_right_bgr + f0 * px * 3, g.W, g.H, nb, h->in_right + f0 * px, h->device, st);
-        return rc;
-    };
     auto depth = [&](int f0, int nb, hipStream_t st) {
         return l3d_depth_from_disp16_device(disp + f0 * px, Q16_host, g.W, g.H, nb, d_depth + f0 * px, nullptr, h->device, st);
     };
+    auto nothing = [](int, int, hipStream_t) { return (int)L3D_OK; };
     if (g.W1 <= 0) {
         // no column has a full disparity range: the matcher fills the map on the caller's stream, the rest follows there
-        int rc = sgbm_run(h, h->in_left, h->in_right, batch, disp, (hipStream_t)stream);
+        int rc = sgbm_run(h, d_left_bgr, d_right_bgr, 3, batch, disp, (hipStream_t)stream, nothing, nothing);
         if (rc == L3D_OK) rc = depth(0, batch, (hipStream_t)stream);
         return rc;
     }
-    // The gray conversions run on the caller's stream ahead of the fork, the reprojection with each half on the handle's
-    // streams (measured: conversions on the two streams as well cost 5 % of the step instead of saving time).
-    auto nothing = [](int, int, hipStream_t) { return (int)L3D_OK; };
-    const int rc = gray(0, batch, (hipStream_t)stream);
-    if (rc) return rc;
-    return sgbm_run(h, h->in_left, h->in_right, batch, disp, (hipStream_t)stream, nothing, depth);
+    // The prefilter reads the colour frames and converts them on the way in (no gray plane is written); the
+    // reprojection runs with each half of the batch on the handle's streams.
+    return sgbm_run(h, d_left_bgr, d_right_bgr, 3, batch, disp, (hipStream_t)stream, nothing, depth);
 }
 
 extern "C" int l3d_sgbm_compute(l3d_sgbm *h, const uint8_t *left, const uint8_t *right, int batch, ptrdiff_t row_stride,
