@@ -68,6 +68,10 @@ __device__ __forceinline__ dim3 xcd_block()
 
 } // namespace l3d
 
+// Disparity -> depth by table look-up (depth.hip); L3D_ERR_UNSUPPORTED when Z depends on the pixel position.
+int depth_from_disp16_lut(const int16_t *d_disp16, const double *Q16_host, size_t npx, float *d_depth, float *d_lut, double *lut_Q,
+                          hipStream_t stream);
+
 // Colour + brightness mask after the 3x3 close and open (stages shared by SimpleLaserExtractor and
 // HybridLaserExtractor); *d_mask points into the handle and stays valid until its next use.  Defined in simple.hip.
 int simple_clean_mask(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const int *lo, const int *hi, int thr, hipStream_t s,

@@ -7,6 +7,7 @@
 // pixels per thread so that its loads and stores are whole dwords).
 #include "common.h"
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace l3d {
@@ -81,6 +82,58 @@ __global__ void __launch_bounds__(256) k_depth(const int16_t *__restrict__ disp1
         if (z > 10.0f) z = 0.0f;
     }
     depth[i] = z;
+}
+
+// When Z does not depend on the pixel position -- the Z and W rows of Q have no x / y terms, which is the form
+// cv2.stereoRectify produces, or there is no Q at all -- the depth of a pixel is a function of its 16-bit disparity
+// alone.  k_depth_lut_build evaluates that function for all 65536 disparity values with exactly the operations of
+// k_depth (at x = y = 0: the x / y products are zeros added first, which changes nothing), and k_depth_lut_apply
+// turns a disparity map into depth by table look-up: one streaming pass with no double-precision division in it.
+__global__ void __launch_bounds__(256) k_depth_lut_build(QMat Q, int calibrated, float *__restrict__ lut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 65535 <-> disparity value i - 32768
+    const float d = (float)(int16_t)(i - 32768) / 16.0f;
+    float z;
+    if (calibrated) {
+        const double dd = (double)d, xd = 0.0, yd = 0.0;
+        double hp[4];
+#pragma unroll
+        for (int r = 2; r < 4; r++) {
+            double s = 0.0;
+            s += Q.q[4 * r + 0] * xd;
+            s += Q.q[4 * r + 1] * yd;
+            s += Q.q[4 * r + 2] * dd;
+            s += Q.q[4 * r + 3] * 1.0;
+            hp[r] = s;
+        }
+        z = (float)((double)(float)hp[2] / hp[3]);
+        if (z < 0.0f) z = 0.0f;
+        if (z > 10.0f) z = 0.0f;
+        if (d <= 0.0f) z = 0.0f;
+    } else {
+        z = 0.0f;
+        if (d > 0.0f) z = (float)((0.06 * 350) / (double)d);
+        if (z > 10.0f) z = 0.0f;
+    }
+    lut[i] = z;
+}
+
+__global__ void __launch_bounds__(256) k_depth_lut_apply(const int16_t *__restrict__ disp16, size_t n, const float *__restrict__ lut,
+                                                         float *__restrict__ depth)
+{
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    if (i0 + 4 <= n && (((uintptr_t)(disp16 + i0)) & 7) == 0 && (((uintptr_t)(depth + i0)) & 15) == 0) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(disp16 + i0);
+        float4 o;
+        o.x = lut[(int)(int16_t)(w.x & 0xffffu) + 32768];
+        o.y = lut[(int)(int16_t)(w.x >> 16) + 32768];
+        o.z = lut[(int)(int16_t)(w.y & 0xffffu) + 32768];
+        o.w = lut[(int)(int16_t)(w.y >> 16) + 32768];
+        *reinterpret_cast<float4 *>(depth + i0) = o;
+    } else {
+        for (size_t i = i0; i < n && i < i0 + 4; i++) depth[i] = lut[(int)disp16[i] + 32768];
+    }
 }
 
 // reconstruct_from_depth for one laser pixel (u, v): true and xyz[0..2] written where the reference appends a point
@@ -358,6 +411,29 @@ extern "C" int l3d_depth_from_disp16_device(const int16_t *d_disp16, const doubl
     else
         hipLaunchKernelGGL(k_depth<false>, grid, block, 0, (hipStream_t)stream, d_disp16, width, height, batch, Q, Q16_host ? 1 : 0, d_depth,
                            d_xyz);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
+// Depth by table look-up for callers that can keep the 65536-entry table (256 KB of device memory): `lut_Q` (17
+// doubles) remembers what the table was built for, [16] = 1 when it holds a calibrated table, 0 for the fallback, -1 when
+// empty.  Returns L3D_ERR_UNSUPPORTED (and does nothing) when Z depends on the pixel position: the caller then uses
+// l3d_depth_from_disp16_device.
+int depth_from_disp16_lut(const int16_t *d_disp16, const double *Q16_host, size_t npx, float *d_depth, float *d_lut, double *lut_Q,
+                          hipStream_t stream)
+{
+    if (Q16_host && (Q16_host[8] != 0.0 || Q16_host[9] != 0.0 || Q16_host[12] != 0.0 || Q16_host[13] != 0.0)) return L3D_ERR_UNSUPPORTED;
+    bool same = lut_Q[16] == (Q16_host ? 1.0 : 0.0);
+    for (int i = 0; i < 16 && same && Q16_host; i++) same = std::memcmp(&lut_Q[i], &Q16_host[i], sizeof(double)) == 0;
+    if (!same) {
+        QMat Q;
+        for (int i = 0; i < 16; i++) Q.q[i] = Q16_host ? Q16_host[i] : 0.0;
+        hipLaunchKernelGGL(k_depth_lut_build, dim3(256), dim3(256), 0, stream, Q, Q16_host ? 1 : 0, d_lut);
+        for (int i = 0; i < 16; i++) lut_Q[i] = Q.q[i];
+        lut_Q[16] = Q16_host ? 1.0 : 0.0;
+    }
+    if (npx)   // (npx = 0: only make sure the table is there)
+        hipLaunchKernelGGL(k_depth_lut_apply, dim3((unsigned)((npx / 4 + 256) / 256)), dim3(256), 0, stream, d_disp16, npx, d_lut, d_depth);
     L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;
 }

@@ -1549,6 +1549,9 @@ struct l3d_sgbm {
     int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
     int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr, *pend = nullptr;
     size_t lds_vertical = 0;
+    // disparity -> depth table of the fused depth entry point (65536 floats) and the Q it was built for
+    float *depth_lut = nullptr;
+    double lut_Q[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1.0};
     // optional per-kernel timing: a ring of event sets, one set per compute call
     static constexpr int NK = 6, RING = 32;
     bool prof = false;
@@ -1591,7 +1594,7 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol, h->Lvol,
-                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend};
+                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend, h->depth_lut};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &set : h->ev)
@@ -1703,6 +1706,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     alloc((void **)&h->dsub, cols * 2);
     alloc((void **)&h->raw, B * px * 2);
     alloc((void **)&h->med, B * px * 2);
+    alloc((void **)&h->depth_lut, 65536 * sizeof(float));
     if (p->speckleWindowSize > 0) {
         alloc((void **)&h->labels, B * px * 4);
         alloc((void **)&h->sizes, B * px * 4);
@@ -1938,7 +1942,11 @@ extern "C" int l3d_sgbm_compute_depth_device(l3d_sgbm *h, const uint8_t *d_left_
     const SgbmGeom &g = h->g;
     const size_t px = (size_t)g.W * g.H;
     int16_t *disp = d_disp ? d_disp : h->out_disp;
+    // Z by table look-up where it depends on the disparity alone (the table is rebuilt on the caller's stream, ahead of
+    // the fork, only when Q changes), else the general kernel
+    const bool lut = depth_from_disp16_lut(disp, Q16_host, 0, d_depth, h->depth_lut, h->lut_Q, (hipStream_t)stream) == L3D_OK;
     auto depth = [&](int f0, int nb, hipStream_t st) {
+        if (lut) return depth_from_disp16_lut(disp + f0 * px, Q16_host, px * nb, d_depth + f0 * px, h->depth_lut, h->lut_Q, st);
         return l3d_depth_from_disp16_device(disp + f0 * px, Q16_host, g.W, g.H, nb, d_depth + f0 * px, nullptr, h->device, st);
     };
     auto nothing = [](int, int, hipStream_t) { return (int)L3D_OK; };

@@ -209,7 +209,9 @@ def test_fused_depth_entry_point_equals_separate_calls(gpu, O):
     R = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
     Q = np.array([[1, 0, 0, -159.5], [0, 1, 0, -89.5], [0, 0, 0, 209.0], [0, 0, 15.94, 0]], np.float64)
     m = _sgbm(**_ref_ctor(D, 5), max_batch=B)
-    for q in (Q, None):
+    Qxy = Q.copy()                      # Z depends on the pixel position: no disparity -> depth table, the general kernel
+    Qxy[2, 1], Qxy[3, 0] = 0.01, 1e-4
+    for q in (Q, None, Qxy, Q):
         for sl in (slice(0, B), slice(3, 4)):
             disp, depth = m.compute_depth_device(L[sl].contiguous(), R[sl].contiguous(), q)
             gl, gr = ops.bgr2gray_device(L[sl].contiguous()), ops.bgr2gray_device(R[sl].contiguous())
