@@ -1292,7 +1292,7 @@ __device__ __forceinline__ void uf_union(int *L, int a, int b)
 // written at pending roots only.  Pending roots are appended to pend_list (*pend_count entries).
 __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp, int W, int H, int newVal, int maxDiff, int maxSize,
                                                       int *__restrict__ labels, int *__restrict__ tsize, int *__restrict__ fsize,
-                                                      int *__restrict__ pend_list, int *__restrict__ pend_count)
+                                                      int *__restrict__ pend_list, int *__restrict__ pend_count, int *__restrict__ tile_pending)
 {
     __shared__ int lab[STH * ST];   // run head of a pixel; for run heads: union-find parent
     __shared__ int cnt[STH * ST];   // at roots: pixel count, bit 31 = touches a shared tile edge
@@ -1355,11 +1355,13 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         }
     }
     __syncthreads();
+    int outv[STH / 4];
+#pragma unroll
     for (int rr = 0; rr < STH / 4; rr++) {
         const int y = wv * (STH / 4) + rr, idx = y * ST + lane, gy = ty0 + y;
+        outv[rr] = -1;
         if (gx >= W || gy >= H) continue;
         const size_t gi = img + (size_t)gy * W + gx;
-        int out = -1;
         const int hd = lab[idx];
         if (hd >= 0) {
             const int root = lab[hd];
@@ -1369,7 +1371,7 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
                 if (n <= maxSize) disp[gi] = (int16_t)newVal;   // complete and small
             } else if (n <= maxSize) {                          // small so far, may continue in another tile
                 const int groot = (int)(img + (size_t)(ty0 + (root >> 6)) * W + tx0 + (root & (ST - 1)));
-                out = groot;
+                outv[rr] = groot;
                 if (idx == root) {
                     tsize[gi] = n;
                     fsize[gi] = n;
@@ -1377,10 +1379,22 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
                 }
             }
         }
-        labels[gi] = out;
     }
     __syncthreads();
-    if (tid == 0 && pn > 0) pbase = atomicAdd(pend_count, pn);
+    // Labels are read again only on the tile's shared edges (by the pass over the edges) and, where the tile has
+    // pending components, by the pass that erases: a tile without any writes its edge pixels only.
+    const bool pending = pn > 0;
+#pragma unroll
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, gy = ty0 + y;
+        if (gx >= W || gy >= H) continue;
+        const bool edge = (lane == 0 && tx0 > 0) || (lane == ST - 1 && gx + 1 < W) || (y == 0 && ty0 > 0) || (y == STH - 1 && gy + 1 < H);
+        if (pending || edge) labels[img + (size_t)gy * W + gx] = outv[rr];
+    }
+    if (tid == 0) {
+        tile_pending[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = pending ? 1 : 0;
+        if (pending) pbase = atomicAdd(pend_count, pn);
+    }
     __syncthreads();
     if (tid < pn) pend_list[pbase + tid] = plist[tid];
 }
@@ -1426,15 +1440,25 @@ __global__ void __launch_bounds__(256) k_speckle_sum(const int *__restrict__ pen
     }
 }
 
-__global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, size_t n, int newVal, int maxSize, const int *__restrict__ labels, const int *__restrict__ fsize)
+// one block per tile; tiles without pending components have nothing to erase
+__global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, int W, int H, int newVal, int maxSize, const int *__restrict__ labels,
+                                                       const int *__restrict__ fsize, const int *__restrict__ tile_pending)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int t = labels[i]; // tile-level root of a pending pixel
-    if (t < 0) return;
-    int r = t, p;
-    while ((p = labels[r]) != r) r = p; // at most a few hops: k_speckle_sum pointed tile roots at final roots
-    if (fsize[r] <= maxSize) disp[i] = (int16_t)newVal;
+    if (!tile_pending[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gx = blockIdx.x * ST + lane;
+    if (gx >= W) return;
+    const size_t img = (size_t)blockIdx.z * W * H;
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int gy = blockIdx.y * STH + wv * (STH / 4) + rr;
+        if (gy >= H) break;
+        const size_t i = img + (size_t)gy * W + gx;
+        const int t = labels[i]; // tile-level root of a pending pixel
+        if (t < 0) continue;
+        int r = t, p;
+        while ((p = labels[r]) != r) r = p; // at most a few hops: k_speckle_sum pointed tile roots at final roots
+        if (fsize[r] <= maxSize) disp[i] = (int16_t)newVal;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1547,7 +1571,7 @@ struct l3d_sgbm {
     uint8_t *rrev = nullptr;
     uint32_t *Cvol = nullptr, *Tvol = nullptr, *Mvol = nullptr, *Lvol = nullptr, *wta = nullptr;
     int16_t *dsub = nullptr, *raw = nullptr, *med = nullptr;
-    int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr, *pend = nullptr;
+    int *labels = nullptr, *sizes = nullptr, *tsizes = nullptr, *pend = nullptr, *tflags = nullptr;
     size_t lds_vertical = 0;
     // disparity -> depth table of the fused depth entry point (65536 floats) and the Q it was built for
     float *depth_lut = nullptr;
@@ -1594,7 +1618,7 @@ extern "C" void l3d_sgbm_destroy(l3d_sgbm *h)
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->in_left, h->in_right, h->out_disp, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol, h->Lvol,
-                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend, h->depth_lut};
+                    h->wta, h->dsub, h->raw, h->med, h->labels, h->sizes, h->tsizes, h->pend, h->tflags, h->depth_lut};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &set : h->ev)
@@ -1712,6 +1736,7 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->sizes, B * px * 4);
         alloc((void **)&h->tsizes, B * px * 4);
         alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, STH) * 256 + 2) * sizeof(int)); // per part of a batch: [0] = count, then the list
+        alloc((void **)&h->tflags, B * cdiv(width, ST) * cdiv(height, STH) * sizeof(int));           // per tile: holds pending components
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -1772,22 +1797,21 @@ template <typename Stamp>
 static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
 {
     const SgbmGeom &g = h->g;
-    const size_t n = (size_t)g.W * g.H * B;
     const bool speckle = g.speckleWindowSize > 0;
     launch_median3(h->raw, g.W, g.H, B, d_disp, s);
     stamp();
     if (speckle) {
         const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
-        const unsigned nb = (unsigned)((n + 255) / 256);
         const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / STH) * g.W);
         L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, STH), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
-                           h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend);
+                           h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend, h->tflags);
         if (pairs)
             hipLaunchKernelGGL(k_speckle_border, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_disp, g.W, g.H, B, newVal, maxDiff, maxSize,
                                h->labels, h->tsizes, h->sizes);
         hipLaunchKernelGGL(k_speckle_sum, dim3(256), dim3(256), 0, s, h->pend + 1, h->pend, h->labels, h->tsizes, h->sizes);
-        hipLaunchKernelGGL(k_speckle_apply, dim3(nb), dim3(256), 0, s, d_disp, n, newVal, maxSize, h->labels, h->sizes);
+        hipLaunchKernelGGL(k_speckle_apply, dim3(cdiv(g.W, ST), cdiv(g.H, STH), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxSize, h->labels,
+                           h->sizes, h->tflags);
     }
     return L3D_OK;
 }
@@ -1816,6 +1840,7 @@ static l3d_sgbm sgbm_view(const l3d_sgbm *h, int f0, int part)
     if (v.labels) {
         v.labels += f * px; v.sizes += f * px; v.tsizes += f * px;
         v.pend += f * cdiv(g.W, ST) * cdiv(g.H, STH) * 256 + part;   // each part: [0] = count, then its list
+        v.tflags += f * cdiv(g.W, ST) * cdiv(g.H, STH);
     }
     return v;
 }
