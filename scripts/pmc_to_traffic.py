@@ -7,6 +7,10 @@ here on k_bgr2gray: 3 B/pixel read -> FETCH_SIZE*2*1024 == 3*W*H*B); WRITE_SIZE 
 
 usage: pmc_to_traffic.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv> [tag] [batch]
        pmc_to_traffic.py --print-only <fetch csv> <write csv>      (prints, leaves profiles/traffic.json alone)
+
+Besides profiles/traffic.json it writes profiles/<tag>_<config>_pmc_per_kernel.csv: per kernel and counter the number
+of dispatches and the mean, minimum and maximum raw counter value (KiB), i.e. the rows of the two rocprofv3 counter
+files reduced to one line per kernel -- what traffic.json is derived from.
 """
 import collections
 import csv
@@ -30,6 +34,13 @@ def per_kernel(path):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def raw_table(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return [(k, counter, len(v), sum(v) / len(v), min(v), max(v)) for k, v in sorted(acc.items())]
+
+
 f, w = per_kernel(ffile), per_kernel(wfile)
 out = {}
 for k in sorted(set(f) | set(w)):
@@ -46,5 +57,9 @@ if not print_only:
     data[cfg + "_batch"] = batch
     data[cfg + "_detail_" + tag] = out
     json.dump(data, open(path, "w"), indent=1)
+    with open(os.path.join(root, "profiles", f"{tag}_{cfg}_pmc_per_kernel.csv"), "w") as out_csv:
+        out_csv.write("kernel,counter,dispatches,mean_KiB,min_KiB,max_KiB\n")
+        for row in raw_table(ffile, "FETCH_SIZE") + raw_table(wfile, "WRITE_SIZE"):
+            out_csv.write("\"%s\",%s,%d,%.3f,%.3f,%.3f\n" % row)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes"]):
     print(f"{k:22s} {v['hbm_bytes'] / 1e6:10.1f} MB / launch   fetch {v.get('fetch_bytes', 0) / 1e6:10.1f}  write {v.get('write_bytes', 0) / 1e6:10.1f}")
