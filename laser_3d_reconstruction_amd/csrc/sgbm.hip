@@ -139,6 +139,16 @@ __device__ __forceinline__ uint32_t group_min_splat(uint32_t v)
     return (uint32_t)m;
 }
 
+// f(integral_constant<K>), f(integral_constant<K+1>), ... up to N - 1, stopping at the first call that returns false:
+// a loop whose counter is a compile-time constant inside the body.
+template <int K, int N, typename F>
+__device__ __forceinline__ void unroll_while(F &&f)
+{
+    if constexpr (K < N) {
+        if (f(std::integral_constant<int, K>{})) unroll_while<K + 1, N>(f);
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
 // outstanding global load and store (vmcnt(0)), which would drain the row prefetch and expose
 // the latency of the volume stores at every row; the tiles exchanged here live in LDS.
@@ -621,7 +631,7 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
 
     // cost of the stripe's first row: rows above it replicate that row
     constexpr int RNR = CSH2 > 0 ? 2 * CSH2 + 1 : 1;
-    uint32_t rr[RNR][NP];   // CSH2 > 0: box sums of rows y-SH2 .. y+SH2, oldest first
+    uint32_t rr[RNR][NP];   // CSH2 > 0: box sums of rows y-SH2 .. y+SH2, oldest first when the row loop starts, then a ring
     auto first_rows = [&](int k, int j) __attribute__((always_inline)) {
         const int kk = min(k, H - 1);
         stage_fetch(kk);
@@ -665,7 +675,15 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     // earlier.  Waiting for a fetch also waits for every older store, so the wait sits a whole
     // iteration after both were issued: by then they have long completed.
     if (start + 1 < end && start + 1 + SH2 <= H - 1) stage_fetch(start + 1 + SH2);
-    for (int y = start; y < end; y++) {
+    // Register ring (CSH2 > 0): the rows are walked in groups of RNR with the group unrolled, so that "the slot of the
+    // oldest row" is a compile-time index k -- the new row's sums replace the oldest row's in place and nothing is
+    // shifted (a shift register cost 2 * CSH2 * NP register moves per row and lane: 54 of ~400 instructions of the
+    // slowest wave at block size 9).
+    for (int y0 = start; y0 < end; y0 += RNR) {
+    unroll_while<0, RNR>([&](auto kc) __attribute__((always_inline)) -> bool {
+        constexpr int k = decltype(kc)::value;
+        const int y = y0 + k;
+        if (y >= end) return false;
         const bool box_now = (y + 1 < end) && (y + 1 + SH2 <= H - 1);
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
         topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
@@ -688,16 +706,16 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
             Pack<NP> sub;
             if (CSH2 > 0) {
 #pragma unroll
-                for (int p = 0; p < NP; p++) sub.v[p] = rr[0][p];
+                for (int p = 0; p < NP; p++) sub.v[p] = rr[k][p];
             } else
                 sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
             if (box_now) {
                 box_row(slot_add, y & 1);
                 box_sum(slot_add);
             } else if (CSH2 > 0) {
-                // below the last image row: that row again, the newest entry of the shift register
+                // below the last image row: that row again, the newest entry of the ring
 #pragma unroll
-                for (int p = 0; p < NP; p++) hs[p] = rr[RNR - 1][p];
+                for (int p = 0; p < NP; p++) hs[p] = rr[(k + RNR - 1) % RNR][p];
             } else {
                 const Pack<NP> o = *reinterpret_cast<const Pack<NP> *>(ring + (slot_last * 256 + tid) * NP);
 #pragma unroll
@@ -705,18 +723,15 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
             }
             if (CSH2 > 0) {
 #pragma unroll
-                for (int r = 0; r + 1 < RNR; r++) {
-#pragma unroll
-                    for (int p = 0; p < NP; p++) rr[r][p] = rr[r + 1][p];
-                }
-#pragma unroll
-                for (int p = 0; p < NP; p++) rr[RNR - 1][p] = hs[p];
+                for (int p = 0; p < NP; p++) rr[k][p] = hs[p];
             }
 #pragma unroll
             for (int p = 0; p < NP; p++) Cst[p] = pk_sub(pk_add(Cst[p], hs[p]), sub.v[p]);
             slot_add = slot_add + 1 == NR ? 0 : slot_add + 1;
             if (y + 1 - SH2 > start) slot_sub = slot_sub + 1 == NR ? 0 : slot_sub + 1;
         }
+        return true;
+    });
     }
 }
 

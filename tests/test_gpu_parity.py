@@ -106,7 +106,8 @@ def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     assert (got[:, :max(mind + D, 0)] == (mind - 1) * 16).all()
 
 
-@pytest.mark.parametrize("W,H,D,b", [(640, 360, 64, 5), (400, 200, 96, 9), (200, 64, 32, 7), (240, 160, 64, 15)])
+@pytest.mark.parametrize("W,H,D,b", [(640, 360, 64, 5), (400, 200, 96, 9), (200, 64, 32, 7), (240, 160, 64, 15), (384, 160, 96, 7),
+                                     (320, 128, 96, 11), (350, 97, 96, 7), (260, 28, 96, 9)])
 def test_sgbm_every_stage_bit_exact_batch_handle(gpu, O, W, H, D, b):
     """A handle for batches (max_batch > 4) runs other kernel variants than a single-frame handle (8 lanes per pixel
     up to 96 disparities instead of 16): the same stage-by-stage check on those."""
