@@ -195,6 +195,12 @@ def main(argv=None):
     if rc is not None:
         return rc
 
+    # stdout carries the one JSON line and nothing else: whatever libraries print on the way (RCCL announces its
+    # version on file descriptor 1 when a communicator is created) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,7 +227,10 @@ def main(argv=None):
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # a process group also for a single rank when it was started by torch.distributed.run: the collectives of the
+    # N > 1 path (broadcast, barrier, all_reduce, all_gather over RCCL) then run on a one-GPU box as well
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -259,14 +268,14 @@ def main(argv=None):
         calib = dict(rig, Q=make_Q(W, H), K=make_K(W, H), map_left_x=rl.maps[0], map_left_y=rl.maps[1],
                      map_right_x=rr.maps[0], map_right_y=rr.maps[1])
     bcast_ms = {}
-    if world > 1:
+    if use_dist:
         small = {k: v for k, v in calib.items() if not k.startswith("map_")} if rank == 0 else None
         torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
         parallel.broadcast_calibration(small, src=0, device=dev)
         torch.cuda.synchronize(); dist.barrier(); bcast_ms["kdrt_q_only"] = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
     calib = parallel.broadcast_calibration(calib, src=0, device=dev)
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize(); dist.barrier(); bcast_ms["with_rectification_maps"] = (time.perf_counter() - t0) * 1e3
         bcast_ms["payload_bytes_with_maps"] = int(sum(np.asarray(v).nbytes for v in calib.values()))
     Q, K = calib["Q"], calib["K"]
@@ -357,7 +366,7 @@ def main(argv=None):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -372,7 +381,7 @@ def main(argv=None):
             step(k)
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -513,7 +522,7 @@ def main(argv=None):
             "timing": {"repeats": len(runs), "reported": "median", "seconds_per_run": runs,
                        "value_min": total_per_step * args.steps / max(runs), "value_max": total_per_step * args.steps / min(runs)},
             "verified": verified,
-            "per_rank_frame_pairs_per_s": per_rank, "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
+            "per_rank_frame_pairs_per_s": per_rank, "rccl_ranks": world if (use_dist and backend == "nccl") else 0,
             "calibration_broadcast_ms": bcast_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
@@ -529,8 +538,9 @@ def main(argv=None):
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
-    if world > 1:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if use_dist:
         dist.destroy_process_group()
     if verified is False:
         print("bench.py: the batch's outputs differ from the single-frame handle's", file=sys.stderr)

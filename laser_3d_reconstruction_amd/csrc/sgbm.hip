@@ -465,14 +465,21 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // kernel): bases advance in scalar registers and the vector ALU spends nothing on addresses.
 // CSH2 > 0: a variant for block size 2*CSH2+1 that keeps the ring of box-sum rows in registers, as a shift register
 // of the 2*CSH2+1 rows of the vertical window (rows above the stripe's first row are copies of it).  With block sizes
-// from 7 on the ring in LDS (42 KB and more per block) leaves two blocks per CU; in registers it leaves three.
+// from 7 on the ring in LDS (42 KB and more per block) leaves two blocks per CU; in registers it leaves three, and
+// four for block size 7 when the kernel is held to 128 registers (a few loop-invariant values spill).
 template <int NP, int LPP, bool PAD, int CSH2 = 0>
-__global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CSH2 == 3 ? 4 : 1)))
+k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
     constexpr int GPB = 256 / LPP;          // image columns per block
-    constexpr int NPS = LPP == 16 ? 3 : 2;  // tile columns per lane group: ceil((GPB + 20) / GPB), blockSize <= 21
     constexpr int CW = NP * LPP;            // u32 per volume column (= D / 2)
+    // The tile has 2*SW2 margin columns beyond the block's own GPB.  Their pixel costs are computed one 32-bit word
+    // (two disparities) per thread, spread over all threads of the block in rounds of 256 words.  (A second
+    // whole-column pass by the first lane groups, the obvious alternative, doubles the work of the first wave, and
+    // the other three wait for it at the barrier.)  The first MRK rounds are unrolled with their staging index in
+    // a register: all rounds of the register-ring variants, and of block sizes up to 5 otherwise.
+    constexpr int MRK = (2 * (CSH2 > 0 ? CSH2 : 2) * CW + 255) / 256;
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     const bool first = l == 0, last = l == LPP - 1;
@@ -521,13 +528,22 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
         s_lidx[e] = s_left[e] ? (uint32_t)(2 * cstride + 6 * w) : (uint32_t)(2 * i); // the second copy lies cstride words further
         s_goff[e] = s_left[e] ? (uint32_t)tile_x(w) * (uint32_t)sizeof(uint2) : (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
     }
-    // byte offset inside a staged plane of the first disparity this lane needs, per tile column
-    uint32_t qword[NPS]; // as a word index into the stage: copy (offset & 1), word (offset >> 1)
+    // byte offset inside a staged plane of the first disparity a lane needs for a tile column, as a word index into
+    // the stage: copy (offset & 1), word (offset >> 1)
+    auto stage_word = [&](int c, int lane) {
+        const int o = x_hi - tile_x(c) + lane * 2 * NP;
+        return (uint32_t)((o & 1) * cstride + (o >> 1));
+    };
+    const uint32_t qword = stage_word(grp, l);
+    // margin word j = word j of the tile behind the block's own columns: (tile column GPB + j / CW, lane, word)
+    const int nmargin = 2 * SW2 * CW;
+    auto margin_word = [&](int j) {
+        const int ch = j / CW, rem = j - ch * CW, lane = rem / NP;
+        return stage_word(GPB + ch, lane) + (uint32_t)(rem - lane * NP);
+    };
+    uint32_t mword[MRK];
 #pragma unroll
-    for (int ps = 0; ps < NPS; ps++) {
-        const int o = x_hi - tile_x(min(grp + GPB * ps, tileC - 1)) + l * 2 * NP;
-        qword[ps] = (uint32_t)((o & 1) * cstride + (o >> 1));
-    }
+    for (int r = 0; r < MRK; r++) mword[r] = margin_word(min(tid + 256 * r, max(nmargin - 1, 0)));
 
     PadFlags<NP, PAD> pad;
     pad.init(l, g.D / 2);
@@ -575,28 +591,43 @@ __global__ void __launch_bounds__(256) k_cost_vertical(SgbmGeom g, const uint2 *
     auto box_row = [&](int slot, int buf) __attribute__((always_inline)) {
         lds_barrier();
         const uint32_t *st = stage + buf * stageW;
+        {
+            const uint32_t *lp = st + 2 * cstride + 6 * grp;
+            const uint32_t u = lp[0], u0 = lp[1], u1 = lp[2], t = lp[3], t0 = lp[4], t1 = lp[5];
+            uint32_t q[6][NP];
 #pragma unroll
-        for (int ps = 0; ps < NPS; ps++) {
-            const int c = grp + GPB * ps;
-            if (c < tileC) {
-                const uint32_t *lp = st + 2 * cstride + 6 * c;
-                const uint32_t u = lp[0], u0 = lp[1], u1 = lp[2], t = lp[3], t0 = lp[4], t1 = lp[5];
-                uint32_t q[6][NP];
+            for (int j = 0; j < 6; j++) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-#pragma unroll
-                    for (int w = 0; w < NP; w++) q[j][w] = st[j * 2 * nd + qword[ps] + w];
-                }
-                Pack<NP> px;
-#pragma unroll
-                for (int p = 0; p < NP; p++) {
-                    const uint32_t cg = bt_pair(u, u0, u1, q[0][p], q[1][p], q[2][p]);
-                    const uint32_t ci = bt_pair(t, t0, t1, q[3][p], q[4][p], q[5][p]);
-                    const v2u two = {2, 2};
-                    px.v[p] = cg + as_u32u(as_v2u(ci) >> two);
-                }
-                *reinterpret_cast<Pack<NP> *>(pixT + (c * LPP + l) * NP) = px;
+                for (int w = 0; w < NP; w++) q[j][w] = st[j * 2 * nd + qword + w];
             }
+            Pack<NP> px;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t cg = bt_pair(u, u0, u1, q[0][p], q[1][p], q[2][p]);
+                const uint32_t ci = bt_pair(t, t0, t1, q[3][p], q[4][p], q[5][p]);
+                const v2u two = {2, 2};
+                px.v[p] = cg + as_u32u(as_v2u(ci) >> two);
+            }
+            *reinterpret_cast<Pack<NP> *>(pixT + (grp * LPP + l) * NP) = px;
+        }
+        auto margin_cost = [&](int j, uint32_t mw) __attribute__((always_inline)) {
+            const uint32_t *lp = st + 2 * cstride + 6 * (GPB + j / CW);
+            const uint32_t u = lp[0], u0 = lp[1], u1 = lp[2], t = lp[3], t0 = lp[4], t1 = lp[5];
+            uint32_t q[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) q[k] = st[k * 2 * nd + mw];
+            const uint32_t cg = bt_pair(u, u0, u1, q[0], q[1], q[2]);
+            const uint32_t ci = bt_pair(t, t0, t1, q[3], q[4], q[5]);
+            const v2u two = {2, 2};
+            pixT[GPB * CW + j] = cg + as_u32u(as_v2u(ci) >> two);
+        };
+#pragma unroll
+        for (int r = 0; r < MRK; r++) {
+            if (tid + 256 * r < nmargin) margin_cost(tid + 256 * r, mword[r]);
+        }
+        if (CSH2 == 0) {
+#pragma unroll 1
+            for (int j = tid + 256 * MRK; j < nmargin; j += 256) margin_cost(j, margin_word(j));
         }
         lds_barrier();
     };
