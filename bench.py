@@ -187,6 +187,8 @@ def main(argv=None):
     ap.add_argument("--steger-stream", default="main", choices=["side", "main"],
                     help="main: the laser extractor runs ahead of the matcher on the step's stream; side: beside it on a stream of its own "
                          "(streams share a few hardware queues: on a side stream it can end up queued in front of one half batch and delay it)")
+    ap.add_argument("--sgbm-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="2: MODE_SGBM_3WAY, the reference's mode and the benchmark; 0 / 1: MODE_SGBM / MODE_HH (5 / 8 paths), GPU leg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args(argv)
@@ -211,7 +213,7 @@ def main(argv=None):
 
     # the CPU leg first: its worker processes are forked, which must happen before this process holds a GPU
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sgbm_mode == 2:
         try:
             cpu = cpu_baseline(W, H, D, block, use_wls, lam, sigma, want_xyz)
         except Exception as e:
@@ -295,7 +297,7 @@ def main(argv=None):
         p = {}
         p["left"] = stereo.StereoSGBM_create(minDisparity=0, numDisparities=D, blockSize=block, P1=8 * 3 * block ** 2,
                                              P2=32 * 3 * block ** 2, disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100,
-                                             speckleRange=32, preFilterCap=63, mode=stereo.STEREO_SGBM_MODE_SGBM_3WAY,
+                                             speckleRange=32, preFilterCap=63, mode=args.sgbm_mode,
                                              device=local_rank, max_batch=batch)
         p["right"] = p["wls"] = None
         if use_wls:
@@ -513,7 +515,7 @@ def main(argv=None):
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "s16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {W}x{H} rectified pairs, SGBM-3WAY D={D} block={block}"
+            "config": {"workload": f"{args.config}: {W}x{H} rectified pairs, SGBM-{('5PATH', '8PATH', '3WAY')[args.sgbm_mode]} D={D} block={block}"
                                    + (f" + right matcher + WLS lambda={lam:g}" if use_wls else "")
                                    + " + depth" + (" + XYZ reprojection" if want_xyz else "") + " + Steger sigma=3.0 + reconstruct_from_depth"
                                    + (" + plane/refraction reconstruction" if want_xyz else ""),

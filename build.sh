@@ -9,7 +9,7 @@ OBJ=laser_3d_reconstruction_amd/csrc/_obj
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -Wno-pass-failed"
 pids=()
-for f in capi sgbm wls depth steger simple remap pointcloud; do
+for f in capi sgbm sgbm_paths wls depth steger simple remap pointcloud; do
     hipcc $FLAGS -c -o $OBJ/$f.o $SRC/$f.hip "$@" &
     pids+=($!)
 done

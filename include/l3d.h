@@ -63,7 +63,8 @@ typedef struct {
     int uniquenessRatio;
     int speckleWindowSize;
     int speckleRange;
-    int mode;              /* 2 = cv2.STEREO_SGBM_MODE_SGBM_3WAY (only mode built) */
+    int mode;              /* 2 = cv2.STEREO_SGBM_MODE_SGBM_3WAY (what the reference passes, :273); 0 = MODE_SGBM (5 paths),
+                              1 = MODE_HH (8 paths); 3 = MODE_HH4 is not built */
 } l3d_sgbm_params;
 
 typedef struct l3d_sgbm l3d_sgbm;

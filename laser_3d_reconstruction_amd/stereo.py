@@ -39,7 +39,8 @@ def _torch_stream_ptr(t):
 
 
 class StereoSGBM:
-    """cv2.StereoSGBM look-alike backed by l3d_sgbm_* (3WAY mode only)."""
+    """cv2.StereoSGBM look-alike backed by l3d_sgbm_*: MODE_SGBM_3WAY (the reference's mode, the fast path), MODE_SGBM and
+    MODE_HH (5 and 8 aggregation paths over the whole image); MODE_HH4 is rejected."""
 
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0,
                  preFilterCap=0, uniquenessRatio=0, speckleWindowSize=0, speckleRange=0,

@@ -141,7 +141,7 @@ typedef struct {
     int uniquenessRatio;
     int speckleWindowSize;
     int speckleRange;
-    int mode; /* 2 = MODE_SGBM_3WAY (the only mode restated) */
+    int mode; /* 2 = MODE_SGBM_3WAY (what the reference uses); 0 = MODE_SGBM (5 paths), 1 = MODE_HH (8 paths) */
 } orc_sgbm_params;
 
 typedef struct {
@@ -451,6 +451,154 @@ static int sgbm_3way(const orc_sgbm_params *p, const uint8_t *left, const uint8_
     return 0;
 }
 
+/* cv2.StereoSGBM.compute, mode = MODE_SGBM (0: one pass, paths from the left, top-left, top, top-right plus a
+ * right->left path, 5 in all) and MODE_HH (1: a second pass bottom->top adds the four opposite paths, 8 in all).
+ * The reference itself always asks for MODE_SGBM_3WAY (camera/single_usb_stereo_camera.py:273); these two modes are
+ * restated from OpenCV 4.x computeDisparitySGBM for callers of the same matcher class.  Parity unpinned.
+ *   - the aggregated cost is the same sliding block sum as above, over the whole image (no stripes), and is stored
+ *     with P2 added to every entry; a path step is L = C' + min(prev[d], prev[d-1]+P1, prev[d+1]+P1, minPrev+P2)
+ *     - (minPrev+P2), so a path entering the image (previous costs all zero) starts with L = C;
+ *   - the summed cost takes the paths by saturating additions in the order left, top-left, top, top-right (first pass),
+ *     right, bottom-left(x-1,y+1), bottom, bottom-right (second pass) resp. the right->left path (MODE_SGBM);
+ *   - winner, uniqueness, sub-pixel step and the left-right check are those of the 3-path mode, run on the rows in
+ *     the order of the last pass. */
+static int sgbm_fulldp(const orc_sgbm_params *p, const uint8_t *left, const uint8_t *right,
+                       int W, int H, int16_t *disp, const sgbm_dumps *dump)
+{
+    sgbm_geom g;
+    int rc = sgbm_geometry(p, W, H, &g);
+    if (rc) return rc;
+    const int D = g.D, W1 = g.W1;
+    if (D > 1024) return -3;
+    for (size_t i = 0; i < (size_t)W * H; i++) disp[i] = (int16_t)g.invalid16;
+    if (W1 <= 0) return 0;
+    const int npasses = p->mode == 1 ? 2 : 1;
+
+    bt_planes bt;
+    bt_planes_alloc(&bt, W, H);
+    bt_planes_fill(&bt, left, right, W, H, g.ftzero);
+
+    const size_t rowN = (size_t)W1 * D;
+    const int NR = 2 * g.SH2 + 2;
+    int16_t *pix = (int16_t *)malloc(rowN * sizeof(int16_t));
+    int16_t *ring = (int16_t *)malloc(rowN * NR * sizeof(int16_t));
+    int *ring_row = (int *)malloc(NR * sizeof(int));
+    int16_t *Cvol = (int16_t *)malloc(rowN * H * sizeof(int16_t));   /* with P2 added */
+    int16_t *Svol = (int16_t *)calloc(rowN * H, sizeof(int16_t));
+    /* path costs of the row in work and of the row before it: [2][W1 + 2 columns][4 paths][D], column c at c + 1 */
+    const size_t lrRow = (size_t)(W1 + 2) * 4 * D;
+    int16_t *Lr = (int16_t *)malloc(2 * lrRow * sizeof(int16_t));
+    int16_t *minLr = (int16_t *)malloc(2 * (size_t)(W1 + 2) * 4 * sizeof(int16_t));
+    int16_t *Rb = (int16_t *)malloc(D * sizeof(int16_t));
+    int16_t *disp2 = (int16_t *)malloc(W * sizeof(int16_t));
+    int16_t *disp2cost = (int16_t *)malloc(W * sizeof(int16_t));
+
+    /* aggregated cost of every row */
+    for (int i = 0; i < NR; i++) ring_row[i] = -1;
+    for (int y = 0; y < H; y++) {
+        int16_t *C = Cvol + (size_t)y * rowN;
+        if (y == 0)
+            for (size_t i = 0; i < rowN; i++) C[i] = (int16_t)g.P2;
+        else
+            memcpy(C, C - rowN, rowN * sizeof(int16_t));
+        int k0 = (y == 0) ? 0 : y + g.SH2, k1 = y + g.SH2;
+        for (int k = k0; k <= k1; k++) {
+            int kk = imin(k, H - 1);
+            int16_t *hs = ring + (size_t)(kk % NR) * rowN;
+            if (ring_row[kk % NR] != kk) {
+                pixcost_row(&g, &bt, kk, pix);
+                hsum_row(&g, pix, hs);
+                ring_row[kk % NR] = kk;
+            }
+            if (y == 0) {
+                int scale = (k == 0) ? g.SH2 + 1 : 1;
+                for (size_t i = 0; i < rowN; i++) C[i] = (int16_t)(C[i] + hs[i] * scale);
+            } else {
+                const int16_t *sub = ring + (size_t)(imax(y - g.SH2 - 1, 0) % NR) * rowN;
+                for (size_t i = 0; i < rowN; i++) C[i] = (int16_t)(C[i] + hs[i] - sub[i]);
+            }
+        }
+    }
+    if (dump && dump->Cvol)   /* without the added P2, as the 3-path mode reports it */
+        for (size_t i = 0; i < rowN * H; i++) dump->Cvol[i] = (int16_t)(Cvol[i] - g.P2);
+
+    for (int pass = 1; pass <= npasses; pass++) {
+        const int y1 = pass == 1 ? 0 : H - 1, y2 = pass == 1 ? H : -1, dy = pass == 1 ? 1 : -1;
+        const int x1 = pass == 1 ? 0 : W1 - 1, x2 = pass == 1 ? W1 : -1, dx = pass == 1 ? 1 : -1;
+        memset(Lr, 0, 2 * lrRow * sizeof(int16_t));
+        memset(minLr, 0, 2 * (size_t)(W1 + 2) * 4 * sizeof(int16_t));
+        int lrID = 0;
+        for (int y = y1; y != y2; y += dy) {
+            const int16_t *C = Cvol + (size_t)y * rowN;
+            int16_t *S = Svol + (size_t)y * rowN;
+            int16_t *cur = Lr + (size_t)lrID * lrRow, *prv = Lr + (size_t)(1 - lrID) * lrRow;
+            int16_t *mcur = minLr + (size_t)lrID * (W1 + 2) * 4, *mprv = minLr + (size_t)(1 - lrID) * (W1 + 2) * 4;
+            for (int x = x1; x != x2; x += dx) {
+                const int16_t *Cp = C + (size_t)x * D;
+                int16_t *Sp = S + (size_t)x * D;
+                /* predecessors: (x - dx, this row), (x - 1, x, x + 1 of the row done before) */
+                const int16_t *pr[4] = {cur + ((size_t)(x - dx + 1) * 4 + 0) * D, prv + ((size_t)(x - 1 + 1) * 4 + 1) * D,
+                                        prv + ((size_t)(x + 1) * 4 + 2) * D, prv + ((size_t)(x + 1 + 1) * 4 + 3) * D};
+                const int pm[4] = {mcur[(x - dx + 1) * 4 + 0], mprv[(x - 1 + 1) * 4 + 1], mprv[(x + 1) * 4 + 2], mprv[(x + 1 + 1) * 4 + 3]};
+                for (int r = 0; r < 4; r++) {
+                    int16_t *out = cur + ((size_t)(x + 1) * 4 + r) * D;
+                    mcur[(x + 1) * 4 + r] = (int16_t)sgm_step(Cp, pr[r], pm[r], D, g.P1, g.P2, out);
+                    for (int d = 0; d < D; d++) Sp[d] = (int16_t)sat16(Sp[d] + out[d]);
+                }
+            }
+            if (pass == npasses) {
+                int16_t *drow = disp + (size_t)y * W;
+                for (int x = 0; x < W; x++) { disp2[x] = (int16_t)g.invalid16; disp2cost[x] = 32767; }
+                memset(Rb, 0, D * sizeof(int16_t));
+                int rightMin = 0;
+                for (int xc = W1 - 1; xc >= 0; xc--) {
+                    int16_t *Sx = S + (size_t)xc * D;
+                    if (npasses == 1) {
+                        rightMin = sgm_step(C + (size_t)xc * D, Rb, rightMin, D, g.P1, g.P2, Rb);
+                        for (int d = 0; d < D; d++) Sx[d] = (int16_t)sat16(Sx[d] + Rb[d]);
+                    }
+                    int best = -1, minS = 32767;
+                    for (int d = 0; d < D; d++)
+                        if (Sx[d] < minS) { minS = Sx[d]; best = d; }
+                    if (best < 0) best = 0;   /* every cost saturated: cannot happen below 32767, kept defined */
+                    int d;
+                    for (d = 0; d < D; d++)
+                        if (Sx[d] * (100 - g.uniq) < minS * 100 && abs(d - best) > 1) break;
+                    if (d < D) continue;
+                    int x2c = xc + g.minX1 - best - g.minD;
+                    if (x2c >= 0 && x2c < W && disp2cost[x2c] > minS) {
+                        disp2cost[x2c] = (int16_t)minS;
+                        disp2[x2c] = (int16_t)(best + g.minD);
+                    }
+                    int dsub;
+                    if (0 < best && best < D - 1) {
+                        int denom2 = imax(Sx[best - 1] + Sx[best + 1] - 2 * Sx[best], 1);
+                        dsub = best * 16 + ((Sx[best - 1] - Sx[best + 1]) * 16 + denom2) / (denom2 * 2);
+                    } else
+                        dsub = best * 16;
+                    drow[xc + g.minX1] = (int16_t)(dsub + g.minD * 16);
+                }
+                for (int x = g.minX1; x < g.maxX1; x++) {
+                    int d1 = drow[x];
+                    if (d1 == g.invalid16) continue;
+                    int _d = d1 >> 4;
+                    int d_ = (d1 + 15) >> 4;
+                    int _x = x - _d, x_ = x - d_;
+                    if (0 <= _x && _x < W && disp2[_x] >= g.minD && abs(disp2[_x] - _d) > g.disp12MaxDiff &&
+                        0 <= x_ && x_ < W && disp2[x_] >= g.minD && abs(disp2[x_] - d_) > g.disp12MaxDiff)
+                        drow[x] = (int16_t)g.invalid16;
+                }
+            }
+            lrID = 1 - lrID;
+        }
+    }
+    if (dump && dump->Svol) memcpy(dump->Svol, Svol, rowN * H * sizeof(int16_t));
+    free(bt.g1); free(pix); free(ring); free(ring_row); free(Cvol); free(Svol); free(Lr); free(minLr);
+    free(Rb); free(disp2); free(disp2cost);
+    if (dump && dump->raw) memcpy(dump->raw, disp, (size_t)W * H * sizeof(int16_t));
+    return 0;
+}
+
 /* G7a: cv::medianBlur(disp, disp, 3) on CV_16S, replicated border */
 ORC_API void orc_median3_s16(const int16_t *src, int W, int H, int16_t *dst)
 {
@@ -513,8 +661,8 @@ ORC_API void orc_filter_speckles(int16_t *img, int W, int H, int newVal, int max
 static int sgbm_full(const orc_sgbm_params *p, const uint8_t *left, const uint8_t *right,
                      int W, int H, int16_t *disp, const sgbm_dumps *dump)
 {
-    if (p->mode != 2) return -10;
-    int rc = sgbm_3way(p, left, right, W, H, disp, dump);
+    if (p->mode < 0 || p->mode > 2) return -10;
+    int rc = p->mode == 2 ? sgbm_3way(p, left, right, W, H, disp, dump) : sgbm_fulldp(p, left, right, W, H, disp, dump);
     if (rc) return rc;
     int16_t *tmp = (int16_t *)malloc((size_t)W * H * sizeof(int16_t));
     orc_median3_s16(disp, W, H, tmp);

@@ -49,7 +49,7 @@ def test_argument_validation_needs_no_gpu():
     from laser_3d_reconstruction_amd import _native as N
 
     h = C.c_void_p()
-    bad_mode = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 0)
+    bad_mode = N.SgbmParams(0, 64, 5, 600, 2400, 1, 63, 10, 100, 32, 3)   # MODE_HH4 is not built
     assert N.lib.l3d_sgbm_create(C.byref(bad_mode), 640, 360, 1, 0, C.byref(h)) == -2
     assert b"3WAY" in N.lib.l3d_last_error()
     bad_d = N.SgbmParams(0, 24, 5, 600, 2400, 1, 63, 10, 100, 32, 2)

@@ -244,7 +244,7 @@ def test_sgbm_edge_cases(gpu, O):
     with pytest.raises(N.L3DError):
         _sgbm(**dict(_ref_ctor(24, 5))).compute(c, c)
     with pytest.raises(N.L3DError):
-        _sgbm(**dict(_ref_ctor(64, 5), mode=0)).compute(c, c)
+        _sgbm(**dict(_ref_ctor(64, 5), mode=3)).compute(c, c)
     with pytest.raises(TypeError):
         _sgbm(**_ref_ctor(32, 5)).compute(c.astype(np.float32), c.astype(np.float32))
     with pytest.raises(ValueError):

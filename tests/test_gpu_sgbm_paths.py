@@ -1,0 +1,93 @@
+"""The 5- and 8-path modes of the matcher (cv2.STEREO_SGBM_MODE_SGBM = 0, MODE_HH = 1) against the oracle, stage by
+stage: aggregated cost of the whole image, summed path costs, disparity before the filters, final disparity.  The
+reference itself always asks for MODE_SGBM_3WAY (camera/single_usb_stereo_camera.py:273); parity unpinned (the oracle
+restates OpenCV's computeDisparitySGBM, no OpenCV here to compare with)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctor(D, b, **over):
+    kw = dict(minDisparity=0, numDisparities=D, blockSize=b, P1=8 * 3 * b * b, P2=32 * 3 * b * b, disp12MaxDiff=1,
+              uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, preFilterCap=63)
+    kw.update(over)
+    return kw
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("W,H,D,b,over", [
+    (640, 360, 64, 5, {}),                                           # the headline shape
+    (400, 200, 96, 9, {}),                                           # 8 lanes per pixel, 6 words a lane
+    (320, 160, 128, 11, {}),                                         # 16 lanes per pixel
+    (333, 131, 64, 3, dict(uniquenessRatio=5, speckleWindowSize=40, speckleRange=2)),   # ragged sizes
+    (200, 64, 32, 7, dict(minDisparity=16, uniquenessRatio=15, disp12MaxDiff=2)),
+    (300, 80, 80, 5, dict(minDisparity=-20)),
+    (260, 70, 144, 5, {}),                                           # padded lane groups (144 of 160 disparities)
+    (240, 100, 64, 19, {}),                                          # P2 = 34656 > 32767
+    (160, 48, 32, 1, dict(P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=-1, preFilterCap=0)),   # defaults applied
+    (140, 20, 16, 5, dict(uniquenessRatio=0, disp12MaxDiff=1000000, speckleWindowSize=0)),      # as a right matcher is set up
+])
+def test_path_modes_every_stage_bit_exact(O, mode, W, H, D, b, over):
+    from laser_3d_reconstruction_amd import stereo
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    kw = _ctor(D, b, **over)
+    lb, rb, _ = S.stereo_pair(W, H, D, 21 + mode)
+    gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+    m = stereo.StereoSGBM_create(**kw, mode=mode)
+    got = m.compute(gl, gr)
+    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw, mode=mode), gl, gr)
+    assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C), "aggregated cost volume"
+    assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.S), "summed path costs"
+    assert np.array_equal(m.fetch_stage(2, 1, W, H)[0], dbg.raw), "disparity before median"
+    assert np.array_equal(got, dbg.disp), "final disparity"
+    assert (got > (kw["minDisparity"] - 1) * 16).mean() > 0.3
+
+
+def test_path_modes_differ_and_batches_equal_single_frames(O):
+    """The three modes give three different maps on the same pair, and a batch (two half batches on two streams from 8
+    frames on) equals its frames run alone."""
+    import torch
+    from laser_3d_reconstruction_amd import stereo
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    W, H, D, b, B = 320, 120, 64, 5, 9
+    pairs = [S.stereo_pair(W, H, D, 70 + k) for k in range(B)]
+    gl = np.stack([O.bgr2gray(p[0]) for p in pairs])
+    gr = np.stack([O.bgr2gray(p[1]) for p in pairs])
+    dev = torch.device("cuda", 0)
+    tl, tr = torch.from_numpy(gl).to(dev), torch.from_numpy(gr).to(dev)
+    maps = {}
+    for mode in (0, 1, 2):
+        big = stereo.StereoSGBM_create(**_ctor(D, b), mode=mode, max_batch=B)
+        one = stereo.StereoSGBM_create(**_ctor(D, b), mode=mode, max_batch=1)
+        d = big.compute_device(tl, tr)
+        torch.cuda.synchronize()
+        for k in (0, 3, 4, 8):
+            assert torch.equal(one.compute_device(tl[k:k + 1], tr[k:k + 1])[0], d[k]), f"mode {mode} frame {k}"
+        want = O.sgbm_compute(O.sgbm_params(**_ctor(D, b), mode=mode), gl[8], gr[8])
+        assert np.array_equal(d[8].cpu().numpy(), want), f"mode {mode} vs oracle"
+        maps[mode] = d[0].cpu().numpy()
+    assert not np.array_equal(maps[0], maps[1]) and not np.array_equal(maps[1], maps[2]) and not np.array_equal(maps[0], maps[2])
+
+
+def test_path_mode_right_matcher_and_wls_chain(O):
+    """createRightMatcher / createDisparityWLSFilter on an 8-path left matcher: the factories copy the mode."""
+    from laser_3d_reconstruction_amd import stereo
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    W, H, D, b = 320, 128, 64, 5
+    lb, rb, _ = S.stereo_pair(W, H, D, 3)
+    gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+    left = stereo.StereoSGBM_create(**_ctor(D, b), mode=stereo.STEREO_SGBM_MODE_HH)
+    right = stereo.createRightMatcher(left)
+    wls = stereo.createDisparityWLSFilter(left)
+    assert right.getMode() == stereo.STEREO_SGBM_MODE_HH
+    dl, dr = left.compute(gl, gr), right.compute(gr, gl)
+    p = O.sgbm_params(**_ctor(D, b), mode=1)
+    assert np.array_equal(dl, O.sgbm_compute(O.wls_left_matcher_params(p), gl, gr))
+    assert np.array_equal(dr, O.sgbm_compute(O.right_matcher_params(p), gr, gl))
+    got = wls.filter(dl, gl, disparity_map_right=dr)
+    want = O.wls_filter(O.wls_params(p, 8000.0, 1.0), dl, dr, gl)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
