@@ -64,6 +64,14 @@ __device__ __forceinline__ dim3 xcd_block()
     const int z = lin / gxy, r = lin - z * gxy, y = r / gx;
     return dim3(r - y * gx, y, z);
 }
+
+// Raw buffer access: descriptor in scalar registers, per-lane byte offset, uniform byte offset.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base)
+{
+    // raw buffer (stride 0), range 2 GiB from `base`, default data format of the gfx9 family
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
 #endif
 
 } // namespace l3d

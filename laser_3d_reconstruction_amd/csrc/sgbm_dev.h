@@ -134,13 +134,6 @@ struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : (NP % 2 == 0 ? 8
     uint32_t v[NP];
 };
 
-// Raw buffer access: descriptor in scalar registers, per-lane byte offset, uniform byte offset.
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-__device__ __forceinline__ BufRsrc make_rsrc(const void *base)
-{
-    // raw buffer (stride 0), range 2 GiB from `base`, default data format of the gfx9 family
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
-}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NP>

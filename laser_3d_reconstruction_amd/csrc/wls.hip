@@ -154,66 +154,78 @@ __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float 
     const int line = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (line >= m) return;
-    const size_t base = (size_t)b * n * m + line;
-    float *a1 = u1 + base, *a2 = u2 + base, *it = inter + base;
-    const float *ww = w + base;
+    // A wave alone on its SIMD is bound by the length of its instruction stream, so addresses cost nothing here: every
+    // access is a buffer access with the line as per-lane offset and the element as a scalar offset, and the element
+    // loops have no per-element bound checks outside their last, partial chunk.
+    const size_t pl = (size_t)b * n * m;
+    const BufRsrc r1 = make_rsrc(u1 + pl), r2 = make_rsrc(u2 + pl), rw = make_rsrc(w + pl), ri = make_rsrc(inter + pl);
+    const uint32_t voff = (uint32_t)line * 4u, rowb = (uint32_t)m * 4u;
+    auto ldf = [&](BufRsrc r, int i) __attribute__((always_inline)) {
+        // (the element index is the same in every lane; saying so keeps the compiler from looping over its values)
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, __builtin_amdgcn_readfirstlane((uint32_t)i * rowb), 0));
+    };
+    auto stf = [&](BufRsrc r, int i, float v) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, __builtin_amdgcn_readfirstlane((uint32_t)i * rowb), 0);
+    };
     float lower = 0.0f, prev_inter = 0.0f, p1 = 0.0f, p2 = 0.0f;
     float cw[FGS_CHUNK], c1[FGS_CHUNK], c2[FGS_CHUNK], nw[FGS_CHUNK], n1[FGS_CHUNK], n2[FGS_CHUNK];
     auto load_fwd = [&](int i0, float (&xw)[FGS_CHUNK], float (&x1)[FGS_CHUNK], float (&x2)[FGS_CHUNK]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < FGS_CHUNK; k++) {
-            const size_t o = (size_t)min(i0 + k, n - 1) * m;   // clamped: the tail of the last chunk is loaded, not used
-            xw[k] = ww[o]; x1[k] = a1[o]; x2[k] = a2[o];
+            const int i = min(i0 + k, n - 1);   // clamped: the tail of the last chunk is loaded, not used
+            xw[k] = ldf(rw, i); x1[k] = ldf(r1, i); x2[k] = ldf(r2, i);
         }
+    };
+    auto fwd = [&](int i, int k) __attribute__((always_inline)) {
+        const float upper = lambda * cw[k];
+        const float denom = (1.0f - lower - upper) - lower * prev_inter;
+        const float ci = upper / denom;
+        const float v1 = (c1[k] - lower * p1) / denom;
+        const float v2 = (c2[k] - lower * p2) / denom;
+        stf(ri, i, ci);
+        stf(r1, i, v1);
+        stf(r2, i, v2);
+        prev_inter = ci; p1 = v1; p2 = v2;
+        lower = upper;
     };
     load_fwd(0, cw, c1, c2);
-    for (int i0 = 0; i0 < n; i0 += FGS_CHUNK) {
+    int i0 = 0;
+    for (; i0 + FGS_CHUNK <= n; i0 += FGS_CHUNK) {
         if (i0 + FGS_CHUNK < n) load_fwd(i0 + FGS_CHUNK, nw, n1, n2);
 #pragma unroll
-        for (int k = 0; k < FGS_CHUNK; k++) {
-            const int i = i0 + k;
-            if (i < n) {
-                const size_t o = (size_t)i * m;
-                const float upper = lambda * cw[k];
-                const float denom = (1.0f - lower - upper) - lower * prev_inter;
-                const float ci = upper / denom;
-                const float v1 = (c1[k] - lower * p1) / denom;
-                const float v2 = (c2[k] - lower * p2) / denom;
-                it[o] = ci;
-                a1[o] = v1;
-                a2[o] = v2;
-                prev_inter = ci; p1 = v1; p2 = v2;
-                lower = upper;
-            }
-        }
+        for (int k = 0; k < FGS_CHUNK; k++) fwd(i0 + k, k);
 #pragma unroll
         for (int k = 0; k < FGS_CHUNK; k++) { cw[k] = nw[k]; c1[k] = n1[k]; c2[k] = n2[k]; }
     }
+#pragma unroll
+    for (int k = 0; k < FGS_CHUNK; k++)
+        if (i0 + k < n) fwd(i0 + k, k);
     // back substitution from element n-2 down; the values it reads were written above by this same thread
-    auto load_bwd = [&](int i0, float (&xw)[FGS_CHUNK], float (&x1)[FGS_CHUNK], float (&x2)[FGS_CHUNK]) __attribute__((always_inline)) {
+    auto load_bwd = [&](int j0, float (&xw)[FGS_CHUNK], float (&x1)[FGS_CHUNK], float (&x2)[FGS_CHUNK]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < FGS_CHUNK; k++) {
-            const size_t o = (size_t)max(i0 - k, 0) * m;
-            xw[k] = it[o]; x1[k] = a1[o]; x2[k] = a2[o];
+            const int i = max(j0 - k, 0);
+            xw[k] = ldf(ri, i); x1[k] = ldf(r1, i); x2[k] = ldf(r2, i);
         }
     };
+    auto bwd = [&](int i, int k) __attribute__((always_inline)) {
+        p1 = c1[k] - cw[k] * p1;
+        p2 = c2[k] - cw[k] * p2;
+        stf(r1, i, p1);
+        stf(r2, i, p2);
+    };
     if (n >= 2) load_bwd(n - 2, cw, c1, c2);
-    for (int i0 = n - 2; i0 >= 0; i0 -= FGS_CHUNK) {
-        if (i0 - FGS_CHUNK >= 0) load_bwd(i0 - FGS_CHUNK, nw, n1, n2);
+    int j0 = n - 2;
+    for (; j0 - (FGS_CHUNK - 1) >= 0; j0 -= FGS_CHUNK) {
+        if (j0 - FGS_CHUNK >= 0) load_bwd(j0 - FGS_CHUNK, nw, n1, n2);
 #pragma unroll
-        for (int k = 0; k < FGS_CHUNK; k++) {
-            const int i = i0 - k;
-            if (i >= 0) {
-                const size_t o = (size_t)i * m;
-                p1 = c1[k] - cw[k] * p1;
-                p2 = c2[k] - cw[k] * p2;
-                a1[o] = p1;
-                a2[o] = p2;
-            }
-        }
+        for (int k = 0; k < FGS_CHUNK; k++) bwd(j0 - k, k);
 #pragma unroll
         for (int k = 0; k < FGS_CHUNK; k++) { cw[k] = nw[k]; c1[k] = n1[k]; c2[k] = n2[k]; }
     }
+#pragma unroll
+    for (int k = 0; k < FGS_CHUNK; k++)
+        if (j0 - k >= 0) bwd(j0 - k, k);
 }
 
 __global__ void __launch_bounds__(256) k_wls_final(const float *__restrict__ u1, const float *__restrict__ u2, int W, int H, int lx0, int rw,
@@ -282,6 +294,8 @@ extern "C" int l3d_wls_create(const l3d_wls_params *p, int width, int height, in
         return L3D_ERR_NO_DEVICE;
     }
     L3D_REQUIRE(device >= 0 && device < ndev, "l3d_wls_create: device %d out of range", device);
+    // the smoother addresses an element of a frame's plane with a 32-bit byte offset
+    L3D_REQUIRE((size_t)width * height * sizeof(float) < (1ull << 31), "l3d_wls_create: %dx%d frames are too large", width, height);
     l3d_wls *h = new (std::nothrow) l3d_wls();
     L3D_REQUIRE(h, "l3d_wls_create: out of host memory");
     h->p = *p; h->W = width; h->H = height; h->device = device; h->max_batch = max_batch;
