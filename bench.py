@@ -180,9 +180,10 @@ def main(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times; the median run is reported")
     ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 64 for C3, 16 for C5; C4: per stream, 32)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--pipelines", type=int, default=None,
-                    help="independent pipelines (matchers + buffers + streams) the steps alternate between; default 2 with the right "
-                         "matcher + WLS (the smoother's line sweeps of one batch run beside the other batch's matchers: +10 %), else 1")
+    ap.add_argument("--pipelines", type=int, default=2,
+                    help="independent pipelines (matchers + buffers + streams) the steps alternate between, so that the tail of one "
+                         "batch runs beside the head of the next (+2 %% at C2; with the right matcher + WLS the smoother's line sweeps "
+                         "of one batch run beside the other batch's matchers: +10 %%)")
     ap.add_argument("--separate-calls", action="store_true", help="gray, matcher and depth as three library calls instead of the fused one")
     ap.add_argument("--steger-stream", default="main", choices=["side", "main"],
                     help="main: the laser extractor runs ahead of the matcher on the step's stream; side: beside it on a stream of its own "
@@ -208,8 +209,6 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     W, H, D, block, use_wls, lam, sigma = CONFIGS[args.config]
     want_xyz = args.config == "C5"
-    if args.pipelines is None:
-        args.pipelines = 2 if use_wls else 1
 
     # the CPU leg first: its worker processes are forked, which must happen before this process holds a GPU
     cpu = None

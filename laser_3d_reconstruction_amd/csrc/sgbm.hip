@@ -222,7 +222,9 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // of the 2*CSH2+1 rows of the vertical window (rows above the stripe's first row are copies of it).  With block sizes
 // from 7 on the ring in LDS (42 KB and more per block) leaves two blocks per CU; in registers it leaves three, and
 // four for block size 7 when the kernel is held to 128 registers (a few loop-invariant values spill).
-template <int NP, int LPP, bool PAD, int CSH2 = 0>
+// BS2 >= 0: a variant for block size 2*BS2+1 with the LDS ring (BS2 = 2 is built for the common shapes): every LDS
+// offset of the row loop is then a compile-time constant and travels in the instructions' offset fields.
+template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CSH2 == 3 ? 4 : 1)))
 k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
@@ -241,7 +243,13 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // logical block: (column block, stripe, frame), column blocks of one stripe adjacent on one XCD
     const dim3 blk = xcd_block();
     const int bx = blk.x, n = blk.y, b = blk.z;
-    const int W = g.W, H = g.H, W1 = g.W1, SW2 = g.SW2, SH2 = g.SH2;
+    constexpr int KS2 = CSH2 > 0 ? CSH2 : BS2;   // half block size when the variant fixes it
+    const int W = g.W, H = g.H, W1 = g.W1, SW2 = KS2 >= 0 ? KS2 : g.SW2, SH2 = KS2 >= 0 ? KS2 : g.SH2;
+    // (the box sums of the register-ring variants take their trip count from the run-time value on purpose: with a
+    // compile-time count the compiler unrolls that loop and hoists every read -- 300 to 440 registers, the kernel
+    // twice as slow)
+    const int SW2box = CSH2 > 0 ? g.SW2 : SW2;
+    constexpr int DP = 2 * CW;              // disparities per volume column (g.Dp)
     const int start = max(min(n * g.stripe_sz - g.stripe_overlap, H), 0);
     const int end = min((n + 1) * g.stripe_sz, H);
     const int own0 = n * g.stripe_sz;
@@ -250,9 +258,9 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // the row leaving it, which is therefore read first (slots are thread-private: no barrier involved).
     const int NR = 2 * SH2 + 1;
     const int tileC = GPB + 2 * SW2;
-    const int nd = (tileC - 1 + g.Dp + 3) / 4 + 1;  // u32 words per staged right-image plane
+    const int nd = (tileC - 1 + DP + 3) / 4 + 1;    // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
-    const int cstride = vertical_copy_stride(tileC, g.Dp);
+    const int cstride = vertical_copy_stride(tileC, DP);
     const int stageW = 2 * cstride + 6 * tileC;     // = vertical_stage_words(tileC, D)
     uint32_t *stage = smem;                         // [2][ 2 copies [cstride >= 6 planes [2 * nd]] | tileC left pixels [6] ]
     uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
@@ -402,7 +410,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
                 for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px[j].v[p]);
             }
         } else
-            for (int j = 0; j <= 2 * SW2; j++) {
+            for (int j = 0; j <= 2 * SW2box; j++) {
                 const Pack<NP> px = *reinterpret_cast<const Pack<NP> *>(pixT + ((grp + j) * LPP + l) * NP);
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = pk_add(hs[p], px.v[p]);
@@ -465,15 +473,19 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // oldest row" is a compile-time index k -- the new row's sums replace the oldest row's in place and nothing is
     // shifted (a shift register cost 2 * CSH2 * NP register moves per row and lane: 54 of ~400 instructions of the
     // slowest wave at block size 9).
-    for (int y0 = start; y0 < end; y0 += RNR) {
-    unroll_while<0, RNR>([&](auto kc) __attribute__((always_inline)) -> bool {
+    // (The variants with a compile-time block size and the LDS ring walk the rows in pairs, so that which of the two
+    // stage buffers a row uses is a compile-time constant as well.)
+    constexpr int GRPN = CSH2 > 0 ? RNR : (BS2 >= 0 ? 2 : 1);
+    for (int y0 = start; y0 < end; y0 += GRPN) {
+    unroll_while<0, GRPN>([&](auto kc) __attribute__((always_inline)) -> bool {
         constexpr int k = decltype(kc)::value;
         const int y = y0 + k;
         if (y >= end) return false;
+        const int buf = (CSH2 == 0 && BS2 >= 0) ? (k & 1) : (y & 1);
         const bool box_now = (y + 1 < end) && (y + 1 + SH2 <= H - 1);
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
         topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
-        if (box_now) stage_put(y & 1);
+        if (box_now) stage_put(buf);
         if (fetch_next) stage_fetch(y + 2 + SH2);
         if (y >= first_stored && active) {
             Pack<NP> pc, pt;
@@ -490,15 +502,15 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         Mout += W1;
         if (y + 1 < end) {
             Pack<NP> sub;
-            if (CSH2 > 0) {
+            if constexpr (CSH2 > 0) {
 #pragma unroll
                 for (int p = 0; p < NP; p++) sub.v[p] = rr[k][p];
             } else
                 sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
             if (box_now) {
-                box_row(slot_add, y & 1);
+                box_row(slot_add, buf);
                 box_sum(slot_add);
-            } else if (CSH2 > 0) {
+            } else if constexpr (CSH2 > 0) {
                 // below the last image row: that row again, the newest entry of the ring
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = rr[(k + RNR - 1) % RNR][p];
@@ -507,7 +519,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = o.v[p];
             }
-            if (CSH2 > 0) {
+            if constexpr (CSH2 > 0) {
 #pragma unroll
                 for (int p = 0; p < NP; p++) rr[k][p] = hs[p];
             }
@@ -1482,6 +1494,13 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
             case 5: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 5>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
             default: break;
             }
+        }
+    }
+    if constexpr (!PAD && ((NP == 4 && LPP == 8) || (NP == 6 && LPP == 8) || (NP == 4 && LPP == 16))) {
+        // block size 5 (the reference's choice for small frames) at 64, 96 and 128 disparities: offsets known at compile time
+        if (g.SW2 == 2 && g.SH2 == 2 && !std::getenv("L3D_SGBM_NO_BS2")) {
+            hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 0, 2>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
+            return;
         }
     }
     hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
