@@ -69,6 +69,9 @@ def test_gray_bit_exact(gpu, O):
     (200, 90, 16, 5, 0, {}),                                           # odd multiples of 16 disparities: 8 lanes per pixel,
     (260, 100, 48, 7, 0, {}),                                          # an odd number of packed words per lane
     (300, 80, 80, 5, -20, {}),
+    (350, 97, 64, 5, -7, {}),                                          # block 5 at 64 / 96 / 128 disparities, ragged sizes
+    (131, 45, 96, 5, 3, {}),
+    (203, 37, 128, 5, 0, {}),
     (330, 72, 112, 3, 0, {}),
     (260, 100, 48, 15, 0, {}),                                         # ... and with both volumes stored
     (300, 64, 144, 5, 0, {}),                                          # odd multiples of 16 above 128: 16 lanes per pixel with
@@ -107,7 +110,9 @@ def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
 
 
 @pytest.mark.parametrize("W,H,D,b", [(640, 360, 64, 5), (400, 200, 96, 9), (200, 64, 32, 7), (240, 160, 64, 15), (384, 160, 96, 7),
-                                     (320, 128, 96, 11), (350, 97, 96, 7), (260, 28, 96, 9)])
+                                     (320, 128, 96, 11), (350, 97, 96, 7), (260, 28, 96, 9),
+                                     # block size 5 at 64 / 96 / 128 disparities (a variant with compile-time LDS layout), ragged sizes
+                                     (350, 97, 64, 5), (130, 44, 96, 5), (200, 36, 128, 5), (97, 24, 64, 5)])
 def test_sgbm_every_stage_bit_exact_batch_handle(gpu, O, W, H, D, b):
     """A handle for batches (max_batch > 4) runs other kernel variants than a single-frame handle (8 lanes per pixel
     up to 96 disparities instead of 16): the same stage-by-stage check on those."""
