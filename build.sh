@@ -13,6 +13,9 @@ for f in capi sgbm sgbm_paths wls depth steger simple remap pointcloud; do
     hipcc $FLAGS -c -o $OBJ/$f.o $SRC/$f.hip "$@" &
     pids+=($!)
 done
+# the horizontal kernel alone is scheduled for instruction-level parallelism (see the head of the file)
+hipcc $FLAGS ${L3D_HORIZONTAL_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp} -c -o $OBJ/sgbm_horizontal.o $SRC/sgbm_horizontal.hip "$@" &
+pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o laser_3d_reconstruction_amd/libl3d_hip.so $OBJ/*.o
 make -s -C oracle

@@ -534,272 +534,6 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: left->right and right->left paths, sum of the three paths, WTA / uniqueness / sub-pixel.
-// One lane group per image row; a wave covers 64/LPP consecutive rows.
-// The left->right costs are needed in right->left order.  Instead of spilling them to HBM the
-// first sweep stores only its state every SEG columns (checkpoints); the second sweep walks the
-// segments right to left, re-runs the left->right recurrence inside the segment from its
-// checkpoint into registers, then runs the right->left recurrence over the same columns.  All
-// loads are issued one segment ahead of their use.
-// ---------------------------------------------------------------------------------------------
-template <int NP, bool TONLY>
-struct SegLen {
-    static constexpr int value = ((NP <= 2 && !TONLY) || (NP == 4 && TONLY)) ? 8 : 4; // TONLY prefetches three operands per column
-};
-
-// The aggregated cost of a column from the path volume: C = T - (min(P[d], P[d-1]+P1, P[d+1]+P1, minP+P2) - (minP+P2)),
-// P = the path costs of the row above, minP their minimum (both halves).  Exact when the recurrence never saturated.
-template <int NP, int LPP>
-__device__ __forceinline__ void cost_from_paths(const uint32_t (&T)[NP], const uint32_t (&P)[NP], uint32_t minP, const SgmPenalty &k, bool first,
-                                                bool last, uint32_t (&C)[NP])
-{
-    const uint32_t BIG = 0x7fff7fffu;
-    const uint32_t mp2v = pk_adds(minP, k.P2a);
-    uint32_t below = LPP < 16 ? dpp_row_any<DPP_ROW_SHR1>(P[NP - 1]) : dpp_row<DPP_ROW_SHR1>(BIG, P[NP - 1]);
-    uint32_t above = LPP < 16 ? dpp_row_any<DPP_ROW_SHL1>(P[0]) : dpp_row<DPP_ROW_SHL1>(BIG, P[0]);
-    if (LPP < 16) {
-        below = first ? BIG : below;
-        above = last ? BIG : above;
-    }
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        const uint32_t lo_src = (p > 0) ? P[p - 1] : below;
-        const uint32_t hi_src = (p < NP - 1) ? P[p + 1] : above;
-        const uint32_t dm1 = __builtin_amdgcn_alignbit(P[p], lo_src, 16);
-        const uint32_t dp1 = __builtin_amdgcn_alignbit(hi_src, P[p], 16);
-        const uint32_t a = pk_adds(pk_min(dm1, dp1), k.P1v);
-        const uint32_t m = pk_min(a, pk_min(P[p], mp2v));
-        C[p] = pk_sub(T[p], pk_subs(m, mp2v));
-    }
-}
-
-// What the horizontal kernel fetches per column: the aggregated cost, or (TONLY) the path costs of the row and of
-// the row above plus the latter's minimum, from which the aggregated cost is rebuilt at the point of use.
-template <int NP, bool TONLY>
-struct ColIn;
-template <int NP>
-struct ColIn<NP, false> {
-    Pack<NP> c;
-};
-template <int NP>
-struct ColIn<NP, true> {
-    Pack<NP> t, p;
-    uint32_t m;
-};
-
-template <int NP, int LPP, bool TONLY, bool PAD>
-__global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
-                                                   const uint32_t *__restrict__ Tvol, const uint32_t *__restrict__ Mvol,
-                                                   uint32_t *__restrict__ ckpt, uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
-{
-    constexpr int SEG = SegLen<NP, TONLY>::value;
-    constexpr int RPW = 64 / LPP; // image rows per wave
-    constexpr int CW = NP * LPP;  // u32 per volume column
-    constexpr int D = 2 * CW;
-    constexpr int REC = D + 8;    // int16 per staged column: the D summed costs and a gap, so best-1 / best+1 stay inside the array
-    // summed costs and keys of one segment, parked for the sub-pixel step that runs once per segment
-    // with one lane per (row, column) instead of once per column with one lane per row
-    __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
-    __shared__ uint32_t sK[RPW * SEG];
-    // results of OSEG segments per row, so that they leave as 64-byte (keys) and 32-byte (disparities) runs:
-    // 16- and 8-byte stores scattered over rows reached HBM as partial lines (+40 % write traffic)
-    constexpr int OSEG = 16 / SEG > 0 ? 16 / SEG : 1, OCOL = OSEG * SEG;
-    __shared__ uint32_t oK[RPW * OCOL];
-    __shared__ int16_t oD[RPW * OCOL];
-    __shared__ __align__(16) uint32_t sWin[(2 * NP + 4) * NP];
-    const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
-    uniq_window_fill<NP>(sWin, tid, 64);
-    __syncthreads();
-    const bool first = l == 0, last = l == LPP - 1;
-    // Vertically adjacent row groups share a row of the volume: they run on one XCD.  (Putting them into one block
-    // of 2 or 4 waves shares that row through the L1 as well and moves 6% fewer bytes, but measured 7-10% slower.)
-    const int row0 = xcd_contiguous(blockIdx.x, gridDim.x) * RPW;
-    // groups past the last row redo the last row (their lanes are needed for the per-segment step) and store nothing
-    const bool row_ok = row0 + grp < nrows_total;
-    const int grp_ld = min(grp, nrows_total - 1 - row0);
-    const int W1 = g.W1;
-    const int nseg = (W1 + SEG - 1) / SEG;
-    constexpr size_t col_bytes = (size_t)CW * sizeof(uint32_t);
-    // block-uniform bases plus a fixed per-lane byte offset (row inside the block, lane inside the column)
-    // volume row of an image row (index over batch * H): plain, or with the stripe padding of the path-only layout
-    auto vol_row = [&](int row) -> size_t {
-        if (!TONLY) return (size_t)row;
-        const int b = row / g.H, y = row - b * g.H;
-        return (size_t)b * g.HR + y + y / g.stripe_sz + 1;
-    };
-    const size_t vrow0 = vol_row(row0) - (TONLY ? 1 : 0);       // uniform base row: one above the first row when the row above is read too
-    const size_t vrel = vol_row(row0 + grp_ld) - vrow0;         // this lane group's row relative to it
-    // Every access is a buffer access: a block-uniform descriptor (base of the block's rows), a uniform byte offset
-    // of the column in a scalar register and a per-lane offset that never changes -- no vector ALU work on addresses.
-    const BufRsrc Cr = make_rsrc(reinterpret_cast<const char *>(Cvol) + (TONLY ? 0 : vrow0 * W1 * col_bytes));
-    const BufRsrc Tr = make_rsrc(reinterpret_cast<const char *>(Tvol) + vrow0 * W1 * col_bytes);
-    const BufRsrc Mr = make_rsrc(reinterpret_cast<const char *>(Mvol) + (TONLY ? vrow0 * W1 * sizeof(uint32_t) : 0));
-    const BufRsrc Kr = make_rsrc(reinterpret_cast<const char *>(ckpt) + (size_t)row0 * nseg * col_bytes);
-    const uint32_t voff = (uint32_t)((vrel * W1 * CW + l * NP) * sizeof(uint32_t));
-    const uint32_t poff = voff - (uint32_t)(TONLY ? W1 * col_bytes : 0);       // the row above
-    const uint32_t moff = (uint32_t)((vrel - (TONLY ? 1 : 0)) * W1 * sizeof(uint32_t));
-    const uint32_t koff = (uint32_t)(((size_t)grp_ld * nseg * CW + l * NP) * sizeof(uint32_t));
-    const SgmPenalty pen = make_penalty(g);
-    const int d0 = l * 2 * NP; // first disparity index held by this lane
-    auto fetch = [&](int x) __attribute__((always_inline)) {
-        const uint32_t xc = (uint32_t)min(max(x, 0), W1 - 1);
-        ColIn<NP, TONLY> r;
-        if constexpr (TONLY) {
-            r.t = buf_load<NP>(Tr, voff, xc * (uint32_t)col_bytes);
-            r.p = buf_load<NP>(Tr, poff, xc * (uint32_t)col_bytes);
-            r.m = __builtin_amdgcn_raw_buffer_load_b32(Mr, moff, xc * (uint32_t)sizeof(uint32_t), 0);
-        } else
-            r.c = buf_load<NP>(Cr, voff, xc * (uint32_t)col_bytes);
-        return r;
-    };
-    auto ldT = [&](int x) __attribute__((always_inline)) { return buf_load<NP>(Tr, voff, (uint32_t)min(max(x, 0), W1 - 1) * (uint32_t)col_bytes); };
-    // aggregated cost of a fetched column, left in place (TONLY: rebuilt into the slot of the row above's costs)
-    auto cost = [&](ColIn<NP, TONLY> &r) __attribute__((always_inline)) -> const uint32_t(&)[NP] {
-        if constexpr (TONLY) {
-            uint32_t c[NP];
-            cost_from_paths<NP, LPP>(r.t.v, r.p.v, r.m, pen, first, last, c);
-#pragma unroll
-            for (int p = 0; p < NP; p++) r.p.v[p] = c[p];
-            return r.p.v;
-        } else
-            return r.c.v;
-    };
-    // role of this lane in the per-segment step: column u of row e_grp
-    const int e_u = tid % SEG, e_grp = tid / SEG;
-    const bool e_on = tid < RPW * SEG && row0 + e_grp < nrows_total;
-    uint32_t *wblk = wta + (size_t)row0 * W1;
-    int16_t *dblk = dsub + (size_t)row0 * W1;
-    const int rows_here = min(RPW, nrows_total - row0);
-
-    // segment being consumed (A) and segment in flight (B)
-    struct Seg {
-        ColIn<NP, TONLY> c[SEG];
-        Pack<NP> t[TONLY ? 1 : SEG]; // !TONLY, sweep 2: the row's path costs
-        Pack<NP> ck;                 // sweep 2: left -> right state at the segment start
-    };
-    Seg A, B;
-
-    // ---- sweep 1: left -> right, keep the state at every segment start ----
-    PadFlags<NP, PAD> pad;
-    pad.init(l, g.D / 2);
-    uint32_t st[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) st[p] = pad.initial(p);
-    uint32_t mn = 0;
-    // The columns pass through a ring of 2 * SEG register slots: the slot of a column is refilled, right after
-    // its use, with the column 2 * SEG further on, so every load has the time of 2 * SEG steps to arrive.  (This
-    // sweep has a third of the arithmetic of the second one per column: with whole segments fetched one segment
-    // ahead it waited for memory.)
-    {
-        constexpr int RING = 2 * SEG;
-        ColIn<NP, TONLY> ring[RING];
-#pragma unroll
-        for (int u = 0; u < RING; u++) ring[u] = fetch(u);
-        for (int x0 = 0; x0 < W1; x0 += RING) {
-#pragma unroll
-            for (int u = 0; u < RING; u++) {
-                const int x = x0 + u;
-                if (x < W1) {
-                    if (u % SEG == 0) {
-                        Pack<NP> o;
-#pragma unroll
-                        for (int p = 0; p < NP; p++) o.v[p] = st[p];
-                        if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)(x / SEG) * (uint32_t)col_bytes);
-                    }
-                    mn = sgm_step<NP, LPP, PAD, !TONLY>(cost(ring[u]), st, mn, pen, first, last, pad);
-                }
-                ring[u] = fetch(x + RING);
-            }
-        }
-    }
-
-    // ---- sweep 2: segments right -> left ----
-    uint32_t rst[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) rst[p] = pad.initial(p);
-    uint32_t rmn = 0;
-    auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
-        const int jc = max(j, 0);
-#pragma unroll
-        for (int u = 0; u < SEG; u++) {
-            s.c[u] = fetch(jc * SEG + u);
-            if constexpr (!TONLY) s.t[u] = ldT(jc * SEG + u);
-        }
-        s.ck = buf_load<NP>(Kr, koff, (uint32_t)jc * (uint32_t)col_bytes);
-    };
-    auto run2 = [&](Seg &s, int j) __attribute__((always_inline)) {
-        // left -> right costs of this segment, recomputed from the checkpoint
-        uint32_t fst[NP], mv = 0x7fff7fffu;
-#pragma unroll
-        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = pk_min(mv, fst[p]); }
-        uint32_t fmn = group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
-        uint32_t Lseg[SEG][NP];
-#pragma unroll
-        for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP, PAD, !TONLY>(cost(s.c[u]), fst, fmn, pen, first, last, pad);
-#pragma unroll
-            for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
-        }
-#pragma unroll
-        for (int u = SEG - 1; u >= 0; u--) {
-            const int xc = j * SEG + u;
-            if (xc < W1) {
-                // (TONLY: cost() already ran on this column in the loop above and left C in place)
-                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
-                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
-                rmn = sgm_step<NP, LPP, PAD, !TONLY>(cu, rst, rmn, pen, first, last, pad);
-                Pack<NP> S;
-#pragma unroll
-                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
-                const uint32_t key = wta_key<NP, LPP>(g, S.v, d0, sWin);
-                *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
-                if (first) sK[grp * SEG + u] = key;
-            }
-        }
-        // per-segment step: one lane per (row, column) fits the parabola and stores the column's result
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
-            const int xc = j * SEG + e_u;
-            if (e_on && xc < W1) {
-                const uint32_t key = sK[tid];
-                int dval = 0;
-                if (key != 0xffffffffu) {
-                    const int best = (int)(key & 0xffffu);
-                    const int16_t *rec = sS + 8 + tid * REC + best;
-                    dval = subpixel_disp(g, best, rec[-1], (int)(key >> 16) - 32768, rec[1]);
-                }
-                const int slot = e_grp * OCOL + (j % OSEG) * SEG + e_u;
-                oK[slot] = key;
-                oD[slot] = (int16_t)dval;
-            }
-        }
-        if (j % OSEG == 0) {
-            // the columns j*SEG .. j*SEG+OCOL-1 of every row are complete
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = tid; i < RPW * OCOL; i += 64) {
-                const int r = i / OCOL, c = i - r * OCOL, x = j * SEG + c;
-                if (r < rows_here && x < W1) {
-                    wblk[(size_t)r * W1 + x] = oK[i];
-                    dblk[(size_t)r * W1 + x] = oD[i];
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    };
-    fetch2(A, nseg - 1);
-    int j = nseg - 1;
-    for (; j >= 1; j -= 2) {
-        // two segments per turn with the buffers swapping roles: no copy of the segment in flight
-        fetch2(B, j - 1);
-        run2(A, j);
-        fetch2(A, j - 2);
-        run2(B, j - 1);
-    }
-    if (j == 0) run2(A, 0);
-}
-
-// ---------------------------------------------------------------------------------------------
 // K4: single-map left-right consistency check; one block per image row.
 // The row is short, so what bounds this kernel is the latency of its dependent loads (key -> right
 // image column -> winner of that column).  Every thread therefore owns LR_ILP columns and issues the
@@ -1506,17 +1240,6 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
     hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
 }
 
-template <int NP, int LPP, bool PAD>
-static void launch_horizontal(l3d_sgbm *h, int B, hipStream_t s)
-{
-    const SgbmGeom &g = h->g;
-    const int nrows = B * g.H;
-    if (g.tonly)
-        hipLaunchKernelGGL((k_horizontal<NP, LPP, true, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
-    else
-        hipLaunchKernelGGL((k_horizontal<NP, LPP, false, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub);
-}
-
 // 3x3 median of h->raw into d_disp, then the speckle filter in place: the tail of StereoSGBM::compute
 template <typename Stamp>
 static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &stamp)
@@ -1587,7 +1310,7 @@ static int sgbm_run_part(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_ri
     stamp();
     bool have_h = true;
     if (g.mode == 2)
-        have_h = dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) { launch_horizontal<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>(h, B, s); });
+        have_h = sgbm_launch_horizontal(g, B, h->Cvol, h->Tvol, h->Mvol, h->Lvol, h->wta, h->dsub, s);
     else if (have_v) {
         // the vertical kernel left the aggregated cost in Cvol (and its top->down path in Tvol, which the first path pass overwrites)
         const int rc = sgbm_paths_aggregate(g, g.mode, B, h->Cvol, h->Tvol, h->wta, h->dsub, s);

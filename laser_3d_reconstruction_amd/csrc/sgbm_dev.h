@@ -356,3 +356,7 @@ static inline bool dispatch_variant(int NP, int LPP, bool pad, F &&f)
 // winner / uniqueness / sub-pixel per column into wta and dsub.  mode: 0 = MODE_SGBM, 1 = MODE_HH.
 int sgbm_paths_aggregate(const l3d::SgbmGeom &g, int mode, int B, const uint32_t *Cvol, uint32_t *Svol, uint32_t *wta, int16_t *dsub,
                          hipStream_t s);
+
+// The horizontal kernel of the 3-path mode (sgbm_horizontal.hip); false when no variant is built for the shape.
+bool sgbm_launch_horizontal(const l3d::SgbmGeom &g, int B, const uint32_t *Cvol, const uint32_t *Tvol, const uint32_t *Mvol, uint32_t *ckpt,
+                            uint32_t *wta, int16_t *dsub, hipStream_t s);
