@@ -263,11 +263,12 @@ __device__ __forceinline__ void uniq_window_fill(uint32_t *window, int tid, int 
     }
 }
 
+// The winner alone: the group-uniform key (biased min S << 16 | argmin); the first minimum wins.
 template <int NP, int LPP>
-__device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, const uint32_t *window)
+__device__ __forceinline__ uint32_t wta_min_key(const uint32_t (&S)[NP], int d0)
 {
-    // per disparity a signed 32-bit key (S << 16 | d): ordering by S, then by d (the first minimum wins); the
-    // disparities of a word sit side by side in dpair[p], so each key is one byte permute
+    // per disparity a signed 32-bit key (S << 16 | d): ordering by S, then by d; the disparities of a word sit side by
+    // side in dpair[p], so each key is one byte permute
     int skey = 0x7fffffff;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -277,7 +278,13 @@ __device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&
         skey = min(skey, min(k0, k1));
     }
     skey = group_min_i32<LPP>(skey);
-    const uint32_t key = (uint32_t)skey ^ 0x80000000u;   // cost biased by 32768: the unsigned form the later stages order by
+    return (uint32_t)skey ^ 0x80000000u;   // cost biased by 32768: the unsigned form the later stages order by
+}
+
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t wta_key(const SgbmGeom &g, const uint32_t (&S)[NP], int d0, const uint32_t *window)
+{
+    const uint32_t key = wta_min_key<NP, LPP>(S, d0);
     if (g.uniq <= 0) return key;
     const int best = (int)(key & 0xffffu);
     const int minS = (int)(key >> 16) - 32768;

@@ -70,8 +70,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     constexpr int CW = NP * LPP;  // u32 per volume column
     constexpr int D = 2 * CW;
     constexpr int REC = D + 8;    // int16 per staged column: the D summed costs and a gap, so best-1 / best+1 stay inside the array
-    // summed costs and keys of one segment, parked for the sub-pixel step that runs once per segment
-    // with one lane per (row, column) instead of once per column with one lane per row
+    // summed costs and winner keys of one segment, parked for the step that runs once per segment: uniqueness test and
+    // sub-pixel fit of the segment's RPW * SEG (row, column) pairs, LPI lanes to a pair.  (Per column, on the lanes that
+    // hold the sums, the uniqueness test costs a table read, two packed operations per word and a reduction over the
+    // group in which every lane computes the same value: 25 instructions per column against 8 here.)
     __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
     __shared__ uint32_t sK[RPW * SEG];
     // results of OSEG segments per row, so that they leave as 64-byte (keys) and 32-byte (disparities) runs:
@@ -79,10 +81,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     constexpr int OSEG = 16 / SEG > 0 ? 16 / SEG : 1, OCOL = OSEG * SEG;
     __shared__ uint32_t oK[RPW * OCOL];
     __shared__ int16_t oD[RPW * OCOL];
-    __shared__ __align__(16) uint32_t sWin[(2 * NP + 4) * NP];
+    constexpr int ITEMS = RPW * SEG, LPI = 64 / ITEMS;   // pairs per segment, lanes per pair
+    constexpr int WPL = CW / LPI;                        // words of a pair's summed costs that one lane scans
+    static_assert(LPI >= 1 && LPI <= 4 && LPI * ITEMS == 64 && WPL % 4 == 0, "per-segment step: lane split");
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
-    uniq_window_fill<NP>(sWin, tid, 64);
-    __syncthreads();
     const bool first = l == 0, last = l == LPP - 1;
     // Vertically adjacent row groups share a row of the volume: they run on one XCD.  (Putting them into one block
     // of 2 or 4 waves shares that row through the L1 as well and moves 6% fewer bytes, but measured 7-10% slower.)
@@ -137,9 +139,11 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
         } else
             return r.c.v;
     };
-    // role of this lane in the per-segment step: column u of row e_grp
-    const int e_u = tid % SEG, e_grp = tid / SEG;
-    const bool e_on = tid < RPW * SEG && row0 + e_grp < nrows_total;
+    // role of this lane in the per-segment step: part e_h of column e_u of row e_grp
+    const int e_item = tid / LPI, e_h = tid % LPI;
+    const int e_u = e_item % SEG, e_grp = e_item / SEG;
+    const bool e_on = e_h == 0 && row0 + e_grp < nrows_total;
+    const int uniq_f = 100 - g.uniq;
     uint32_t *wblk = wta + (size_t)row0 * W1;
     int16_t *dblk = dsub + (size_t)row0 * W1;
     const int rows_here = min(RPW, nrows_total - row0);
@@ -224,26 +228,62 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 Pack<NP> S;
 #pragma unroll
                 for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
-                const uint32_t key = wta_key<NP, LPP>(g, S.v, d0, sWin);
+                const uint32_t key = wta_min_key<NP, LPP>(S.v, d0);
                 *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
                 if (first) sK[grp * SEG + u] = key;
             }
         }
-        // per-segment step: one lane per (row, column) fits the parabola and stores the column's result
+        // per-segment step: uniqueness test and parabola fit per (row, column)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {
             const int xc = j * SEG + e_u;
-            if (e_on && xc < W1) {
-                const uint32_t key = sK[tid];
-                int dval = 0;
-                if (key != 0xffffffffu) {
-                    const int best = (int)(key & 0xffffu);
-                    const int16_t *rec = sS + 8 + tid * REC + best;
-                    dval = subpixel_disp(g, best, rec[-1], (int)(key >> 16) - 32768, rec[1]);
+            const uint32_t key = sK[e_item];
+            const int best = xc < W1 ? (int)(key & 0xffffu) : 0;   // columns past the row's end hold nothing: stay inside the record
+            const int sc = (int)(key >> 16) - 32768;
+            int16_t *rec = sS + 8 + e_item * REC;
+            const int sm = rec[best - 1], sp = rec[best + 1];
+            bool reject = false;
+            if (g.uniq > 0) {
+                // rejected when some d outside best-1 .. best+1 has S[d] * (100 - uniq) < min S * 100, i.e. when the smallest
+                // such S[d] has (the largest, should 100 - uniq be negative): the three entries are overwritten with a
+                // value that cannot win, then the record is scanned, each of the pair's lanes taking a part
+                const bool lo = uniq_f > 0;
+                const int16_t never = lo ? (int16_t)32767 : (int16_t)-32768;
+                if (e_h == 0) { rec[best - 1] = never; rec[best] = never; rec[best + 1] = never; }
+                const u32x4 *q = reinterpret_cast<const u32x4 *>(rec + e_h * 2 * WPL);
+                int m;
+                if (lo) {
+                    uint32_t acc = 0x7fff7fffu;
+#pragma unroll
+                    for (int k = 0; k < WPL / 4; k++) {
+                        const u32x4 v = q[k];
+                        acc = pk_min(acc, pk_min(pk_min(v.x, v.y), pk_min(v.z, v.w)));
+                    }
+                    m = (int)pk_min(acc, __builtin_amdgcn_alignbit(acc, acc, 16));
+                    if (LPI >= 2) m = min(m, (int)dpp_row<DPP_QUAD_XOR1>(0x7fffffffu, (uint32_t)m));
+                    if (LPI >= 4) m = min(m, (int)dpp_row<DPP_QUAD_XOR2>(0x7fffffffu, (uint32_t)m));
+                } else {
+                    uint32_t acc = 0x80008000u;
+#pragma unroll
+                    for (int k = 0; k < WPL / 4; k++) {
+                        u32x4 v = q[k];
+                        if (PAD) {   // the padding entries hold 32767: not part of the range
+                            const int w0 = e_h * WPL + 4 * k, real = g.D / 2;
+                            v.x = w0 < real ? v.x : 0x80008000u; v.y = w0 + 1 < real ? v.y : 0x80008000u;
+                            v.z = w0 + 2 < real ? v.z : 0x80008000u; v.w = w0 + 3 < real ? v.w : 0x80008000u;
+                        }
+                        acc = pk_max(acc, pk_max(pk_max(v.x, v.y), pk_max(v.z, v.w)));
+                    }
+                    m = (int)pk_max(acc, __builtin_amdgcn_alignbit(acc, acc, 16));
+                    if (LPI >= 2) m = max(m, (int)dpp_row<DPP_QUAD_XOR1>(0x80000000u, (uint32_t)m));
+                    if (LPI >= 4) m = max(m, (int)dpp_row<DPP_QUAD_XOR2>(0x80000000u, (uint32_t)m));
                 }
+                reject = (int)(short)(m & 0xffff) * uniq_f < sc * 100;
+            }
+            if (e_on && xc < W1) {
                 const int slot = e_grp * OCOL + (j % OSEG) * SEG + e_u;
-                oK[slot] = key;
-                oD[slot] = (int16_t)dval;
+                oK[slot] = reject ? 0xffffffffu : key;
+                oD[slot] = (int16_t)(reject ? 0 : subpixel_disp(g, best, sm, sc, sp));
             }
         }
         if (j % OSEG == 0) {

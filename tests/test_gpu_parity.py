@@ -88,6 +88,11 @@ def test_gray_bit_exact(gpu, O):
     (350, 97, 96, 7, -40, {}),                                         # ... ragged height, negative minDisparity
     (260, 28, 96, 7, 0, {}),                                           # ... stripes barely taller than their overlap
     (200, 40, 128, 11, 0, {}),
+    (320, 60, 64, 5, 0, dict(uniquenessRatio=100)),                    # 100 - uniquenessRatio = 0 and < 0: the test turns into
+    (320, 60, 64, 5, 0, dict(uniquenessRatio=130)),                    # one on the largest summed cost outside the window
+    (300, 48, 144, 5, 0, dict(uniquenessRatio=130)),                   # ... with padding disparities in the record
+    (260, 60, 96, 9, 0, dict(uniquenessRatio=40)),                     # two and four lanes to a column in the uniqueness scan
+    (300, 40, 256, 5, 0, dict(uniquenessRatio=25)),
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
