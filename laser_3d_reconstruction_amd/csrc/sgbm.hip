@@ -224,7 +224,9 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // four for block size 7 when the kernel is held to 128 registers (a few loop-invariant values spill).
 // BS2 >= 0: a variant for block size 2*BS2+1 with the LDS ring (BS2 = 2 is built for the common shapes): every LDS
 // offset of the row loop is then a compile-time constant and travels in the instructions' offset fields.
-template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1>
+// UF: the path costs carry an offset of P2 and the recurrence runs in its unsigned form (SgbmGeom::uform); the volume
+// then holds T + P2 and the per-column minimum + P2.
+template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1, bool UF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CSH2 == 3 ? 4 : 1)))
 k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
@@ -312,8 +314,8 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     pad.init(l, g.D / 2);
     uint32_t Cst[NP], Tst[NP], hs[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = pad.initial(p); }
-    uint32_t topMin = 0;
+    for (int p = 0; p < NP; p++) { Cst[p] = 0; Tst[p] = UF ? pen.P2a : pad.initial(p); }
+    uint32_t topMin = UF ? pen.P2a : 0u;
     uint32_t sreg_lo[kStageLoadsMax], sreg_hi[kStageLoadsMax];
 
     auto stage_fetch = [&](int k) __attribute__((always_inline)) {
@@ -451,6 +453,10 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     } else {
         for (int k = start; k <= start + SH2; k++) first_rows(k, 0);
     }
+    if (UF) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pen.P2a);
+    }
 
     const uint32_t voff = (uint32_t)(((size_t)xc_own * CW + l * NP) * sizeof(uint32_t));
     const size_t row_bytes = (size_t)W1 * CW * sizeof(uint32_t);
@@ -484,7 +490,8 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         const int buf = (CSH2 == 0 && BS2 >= 0) ? (k & 1) : (y & 1);
         const bool box_now = (y + 1 < end) && (y + 1 + SH2 <= H - 1);
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
-        topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
+        if constexpr (UF) topMin = sgm_step_u<NP, LPP>(Cst, Tst, topMin, pen, first, last);
+        else topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
         if (box_now) stage_put(buf);
         if (fetch_next) stage_fetch(y + 2 + SH2);
         if (y >= first_stored && active) {
@@ -928,6 +935,13 @@ __global__ void __launch_bounds__(256) k_speckle_apply(int16_t *disp, int W, int
     }
 }
 
+// Fills the first `n` 16-bit entries of every frame's slice (stride in entries) with `v`.
+__global__ void __launch_bounds__(256) k_fill16(uint16_t *base, size_t frame_stride, size_t n, uint16_t v)
+{
+    uint16_t *o = base + (size_t)blockIdx.y * frame_stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -963,6 +977,7 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     g->tonly = g->P2 <= 32767 && max_c <= 32767 && p->mode == 2;
     if (const char *ov = std::getenv("L3D_SGBM_TONLY"))
         if (std::atoi(ov) == 0) g->tonly = 0;
+    g->uform = 0;   // decided below, once the lane-group shape (padding disparities or not) is known
     // 8 lanes per pixel halve the wave steps per pixel and amortise the per-step overhead; both kernels gain from
     // that up to 96 disparities (measured: slower again at 128) -- the horizontal one only in the path-only scheme, where it is bound by vector
     // instructions; with both volumes it is bound by memory stalls and needs the wave count of 16 lanes per row.
@@ -992,6 +1007,12 @@ int sgbm_make_geom(const l3d_sgbm_params *p, int W, int H, SgbmGeom *g)
     g->NPv = g->Dp / (2 * g->LPPv);
     g->NPh = g->Dp / (2 * g->LPPh);
     g->HR = g->H + 4;
+    // the unsigned form of the recurrence: every path cost lies in [-P2, max_c], so with P2 added it is non-negative;
+    // previous minimum + P2 <= max_c + P2 and the sum of two paths <= 2 * max_c must not reach the saturation value of
+    // the signed form, and 3 * P2 (the offset of the three summed paths) must be a 16-bit value
+    g->uform = g->tonly && g->Dp == g->D && max_c + g->P2 <= 32767 && 2 * max_c <= 32767 && 3LL * g->P2 <= 32767;
+    if (const char *ov = std::getenv("L3D_SGBM_UFORM"))
+        if (std::atoi(ov) == 0) g->uform = 0;
     return 0;
 }
 
@@ -1190,6 +1211,14 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         alloc((void **)&h->pend, (B * cdiv(width, ST) * cdiv(height, STH) * 256 + 2) * sizeof(int)); // per part of a batch: [0] = count, then the list
         alloc((void **)&h->tflags, B * cdiv(width, ST) * cdiv(height, STH) * sizeof(int));           // per tile: holds pending components
     }
+    if (e == hipSuccess && g.uform && g.W1 > 0) {
+        // the row above a frame's first row holds the state a path starts from: zero costs, i.e. P2 in the offset form
+        const size_t row = (size_t)g.W1 * g.Dp;
+        hipLaunchKernelGGL(k_fill16, dim3(64, (unsigned)B), dim3(256), 0, h->stream, (uint16_t *)h->Tvol, (size_t)g.HR * row, row, (uint16_t)g.P2);
+        hipLaunchKernelGGL(k_fill16, dim3(8, (unsigned)B), dim3(256), 0, h->stream, (uint16_t *)h->Mvol, (size_t)g.HR * g.W1 * 2, (size_t)g.W1 * 2,
+                           (uint16_t)g.P2);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         set_error("l3d_sgbm_create: allocation failed: %s", hipGetErrorString(e));
@@ -1201,8 +1230,13 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         const size_t lds = h->lds_vertical;
         e = hipErrorInvalidValue;
         dispatch_variant(g.NPv, g.LPPv, g.Dp != g.D, [&](auto np, auto lpp, auto pd) {
-            e = hipFuncSetAttribute((const void *)k_cost_vertical<decltype(np)::value, decltype(lpp)::value, decltype(pd)::value>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            constexpr int NP = decltype(np)::value, LPP = decltype(lpp)::value;
+            constexpr bool PAD = decltype(pd)::value;
+            e = hipFuncSetAttribute((const void *)k_cost_vertical<NP, LPP, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if constexpr (!PAD) {
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void *)k_cost_vertical<NP, LPP, PAD, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            }
         });
         if (e != hipSuccess) {
             set_error("l3d_sgbm_create: cannot reserve %zu B of LDS: %s", h->lds_vertical, hipGetErrorString(e));
@@ -1214,8 +1248,8 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
     return L3D_OK;
 }
 
-template <int NP, int LPP, bool PAD>
-static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
+template <int NP, int LPP, bool PAD, bool UF>
+static void launch_vertical_form(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
@@ -1223,9 +1257,9 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
         // the block sizes with a register-ring variant (see vertical_ring_in_regs)
         if (g.ring_regs) {
             switch (g.SH2) {
-            case 3: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 3>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
-            case 4: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 4>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
-            case 5: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 5>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 3: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 3, -1, UF>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 4: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 4, -1, UF>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 5: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 5, -1, UF>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
             default: break;
             }
         }
@@ -1233,11 +1267,23 @@ static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
     if constexpr (!PAD && ((NP == 4 && LPP == 8) || (NP == 6 && LPP == 8) || (NP == 4 && LPP == 16))) {
         // block size 5 (the reference's choice for small frames) at 64, 96 and 128 disparities: offsets known at compile time
         if (g.SW2 == 2 && g.SH2 == 2 && !std::getenv("L3D_SGBM_NO_BS2")) {
-            hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 0, 2>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
+            hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 0, 2, UF>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
             return;
         }
     }
-    hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
+    hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 0, -1, UF>), gv, dim3(256), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol);
+}
+
+template <int NP, int LPP, bool PAD>
+static void launch_vertical(l3d_sgbm *h, int B, hipStream_t s)
+{
+    if constexpr (!PAD) {
+        if (h->g.uform) {
+            launch_vertical_form<NP, LPP, PAD, true>(h, B, s);
+            return;
+        }
+    }
+    launch_vertical_form<NP, LPP, PAD, false>(h, B, s);
 }
 
 // 3x3 median of h->raw into d_disp, then the speckle filter in place: the tail of StereoSGBM::compute
@@ -1481,8 +1527,10 @@ extern "C" int l3d_sgbm_postfilter(l3d_sgbm *h, const int16_t *raw, int batch, i
 // Host-side rebuild of the stage volumes [B][H][W1][D] from the device layout (stage-level checks only).
 // Path-only layout: T rows are gathered out of the volume with its stripe padding rows; C = T - (what the
 // recurrence added from the row above), in plain integers.  Columns are Dp wide on the device, D here.
-static void stage_unpack(const SgbmGeom &g, const std::vector<int16_t> &dev, int B, int stage, int16_t *dst)
+static void stage_unpack(const SgbmGeom &g, std::vector<int16_t> &dev, int B, int stage, int16_t *dst)
 {
+    if (g.uform)   // the device volume holds T + P2
+        for (int16_t &v : dev) v = (int16_t)(uint16_t)((uint16_t)v - (uint16_t)g.P2);
     const size_t col = (size_t)g.Dp, row = (size_t)g.W1 * col, ocol = (size_t)g.D, orow = (size_t)g.W1 * ocol;
     const int P1 = std::min(g.P1, 32767);
     for (int b = 0; b < B; b++)

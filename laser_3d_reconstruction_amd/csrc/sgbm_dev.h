@@ -29,6 +29,10 @@ struct SgbmGeom {
     // vertical kernel: the ring of box-sum rows lives in registers (a kernel variant built for this block size)
     // instead of LDS
     int ring_regs;
+    // Path costs are kept with P2 added (so they are non-negative) and the recurrence runs in its unsigned form
+    // (sgm_step_u), which needs one instruction less per packed word.  Set when nothing can saturate: path-only layout,
+    // no padding disparities, max cost + P2 <= 32767, 2 * max cost <= 32767 and 3 * P2 <= 32767.
+    int uform;
     // 2 = the 3-path mode (four stripes); 0 / 1 = the 5- / 8-path modes: one stripe over the whole image, both volumes
     // stored (the second one serves as the sum volume), the paths run by sgbm_paths.hip
     int mode;
@@ -246,6 +250,53 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&c)[NP], uint32_t (
 #pragma unroll
     for (int p = 0; p < NP; p++) st[p] = out[p];
     return group_min_splat<LPP>(mn);
+}
+
+// The same recurrence on costs that carry an offset of P2 (state' = state + P2 >= 0, c' = c + P2, prevMin' = prevMin + P2),
+// valid when no operation of the signed form can saturate (SgbmGeom::uform).  With m = prevMin' + P2:
+//   out'[d] = c'[d] - w[d],   w[d] = m - min(st'[d], st'[d-1] + P1, st'[d+1] + P1, m)
+//                                  = max(e[d], max(e[d-1], e[d+1]) -sat P1),   e[d] = m -sat st'[d]
+// in unsigned saturating arithmetic: the subtraction that clamps at zero does the work of one of the minima.  A missing
+// neighbour contributes e = 0, which is what a DPP move delivers to a lane without a source.
+template <int NP, int LPP>
+__device__ __forceinline__ void sgm_excess(const uint32_t (&st)[NP], uint32_t m, uint32_t P1v, bool first, bool last, uint32_t (&w)[NP])
+{
+    uint32_t e[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) e[p] = pku_subs(m, st[p]);
+    uint32_t below = dpp_row_any<DPP_ROW_SHR1>(e[NP - 1]); // lane-1's top pair
+    uint32_t above = dpp_row_any<DPP_ROW_SHL1>(e[0]);      // lane+1's bottom pair
+    if (LPP < 16) {
+        below = first ? 0u : below;
+        above = last ? 0u : above;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const uint32_t lo_src = (p > 0) ? e[p - 1] : below;
+        const uint32_t hi_src = (p < NP - 1) ? e[p + 1] : above;
+        const uint32_t dm1 = __builtin_amdgcn_alignbit(e[p], lo_src, 16);
+        const uint32_t dp1 = __builtin_amdgcn_alignbit(hi_src, e[p], 16);
+        w[p] = pku_max(e[p], pku_subs(pku_max(dm1, dp1), P1v));
+    }
+}
+// Minimum over both uint16 halves of `v` and over the lanes of the group, in both halves of the result.
+template <int LPP>
+__device__ __forceinline__ uint32_t group_min_splat_u(uint32_t v)
+{
+    return group_min_u32<LPP>(pku_min(v, __builtin_amdgcn_alignbit(v, v, 16)));
+}
+template <int NP, int LPP>
+__device__ __forceinline__ uint32_t sgm_step_u(const uint32_t (&c)[NP], uint32_t (&st)[NP], uint32_t prevMin, const SgmPenalty &k, bool first, bool last)
+{
+    uint32_t w[NP];
+    sgm_excess<NP, LPP>(st, pk_add(prevMin, k.P2a), k.P1v, first, last, w);
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        st[p] = pk_sub(c[p], w[p]);
+        mn = pku_min(mn, st[p]);
+    }
+    return group_min_splat_u<LPP>(mn);
 }
 
 // Winner-take-all and uniqueness test for one column from the summed costs S, on all lanes of the

@@ -22,10 +22,18 @@ struct SegLen {
 
 // The aggregated cost of a column from the path volume: C = T - (min(P[d], P[d-1]+P1, P[d+1]+P1, minP+P2) - (minP+P2)),
 // P = the path costs of the row above, minP their minimum (both halves).  Exact when the recurrence never saturated.
-template <int NP, int LPP>
+// UF: the volume holds the path costs with P2 added and the result is the aggregated cost with P2 added (sgm_step_u).
+template <int NP, int LPP, bool UF>
 __device__ __forceinline__ void cost_from_paths(const uint32_t (&T)[NP], const uint32_t (&P)[NP], uint32_t minP, const SgmPenalty &k, bool first,
                                                 bool last, uint32_t (&C)[NP])
 {
+    if constexpr (UF) {
+        uint32_t w[NP];
+        sgm_excess<NP, LPP>(P, pk_add(minP, k.P2a), k.P1v, first, last, w);
+#pragma unroll
+        for (int p = 0; p < NP; p++) C[p] = pk_add(T[p], w[p]);
+        return;
+    }
     const uint32_t BIG = 0x7fff7fffu;
     const uint32_t mp2v = pk_adds(minP, k.P2a);
     uint32_t below = LPP < 16 ? dpp_row_any<DPP_ROW_SHR1>(P[NP - 1]) : dpp_row<DPP_ROW_SHR1>(BIG, P[NP - 1]);
@@ -60,7 +68,7 @@ struct ColIn<NP, true> {
     uint32_t m;
 };
 
-template <int NP, int LPP, bool TONLY, bool PAD>
+template <int NP, int LPP, bool TONLY, bool PAD, bool UF>
 __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, const uint32_t *__restrict__ Cvol,
                                                    const uint32_t *__restrict__ Tvol, const uint32_t *__restrict__ Mvol,
                                                    uint32_t *__restrict__ ckpt, uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
@@ -132,12 +140,19 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     auto cost = [&](ColIn<NP, TONLY> &r) __attribute__((always_inline)) -> const uint32_t(&)[NP] {
         if constexpr (TONLY) {
             uint32_t c[NP];
-            cost_from_paths<NP, LPP>(r.t.v, r.p.v, r.m, pen, first, last, c);
+            cost_from_paths<NP, LPP, UF>(r.t.v, r.p.v, r.m, pen, first, last, c);
 #pragma unroll
             for (int p = 0; p < NP; p++) r.p.v[p] = c[p];
             return r.p.v;
         } else
             return r.c.v;
+    };
+    PadFlags<NP, PAD> pad;
+    pad.init(l, g.D / 2);
+    // one step of a horizontal path
+    auto path_step = [&](const uint32_t(&c)[NP], uint32_t(&stt)[NP], uint32_t pm) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (UF) return sgm_step_u<NP, LPP>(c, stt, pm, pen, first, last);
+        else return sgm_step<NP, LPP, PAD, !TONLY>(c, stt, pm, pen, first, last, pad);
     };
     // role of this lane in the per-segment step: part e_h of column e_u of row e_grp
     const int e_item = tid / LPI, e_h = tid % LPI;
@@ -157,12 +172,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     Seg A, B;
 
     // ---- sweep 1: left -> right, keep the state at every segment start ----
-    PadFlags<NP, PAD> pad;
-    pad.init(l, g.D / 2);
     uint32_t st[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) st[p] = pad.initial(p);
-    uint32_t mn = 0;
+    for (int p = 0; p < NP; p++) st[p] = UF ? pen.P2a : pad.initial(p);   // a path starts from zero costs (UF: + P2)
+    uint32_t mn = UF ? pen.P2a : 0u;
     // The columns pass through a ring of 2 * SEG register slots: the slot of a column is refilled, right after
     // its use, with the column 2 * SEG further on, so every load has the time of 2 * SEG steps to arrive.  (This
     // sweep has a third of the arithmetic of the second one per column: with whole segments fetched one segment
@@ -183,7 +196,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                         for (int p = 0; p < NP; p++) o.v[p] = st[p];
                         if (row_ok) buf_store<NP>(o, Kr, koff, (uint32_t)(x / SEG) * (uint32_t)col_bytes);
                     }
-                    mn = sgm_step<NP, LPP, PAD, !TONLY>(cost(ring[u]), st, mn, pen, first, last, pad);
+                    mn = path_step(cost(ring[u]), st, mn);
                 }
                 ring[u] = fetch(x + RING);
             }
@@ -193,8 +206,11 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // ---- sweep 2: segments right -> left ----
     uint32_t rst[NP];
 #pragma unroll
-    for (int p = 0; p < NP; p++) rst[p] = pad.initial(p);
-    uint32_t rmn = 0;
+    for (int p = 0; p < NP; p++) rst[p] = UF ? pen.P2a : pad.initial(p);
+    uint32_t rmn = UF ? pen.P2a : 0u;
+    // UF: the left -> right costs enter the sum with 3 * P2 taken off, which is the offset of the three summands together:
+    // (R' + (L' - 3 P2)) + T' = R + L + T, the last addition saturating as in the definition (the first cannot)
+    const uint32_t P2x3 = pk_splat(3 * g.P2);
     auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
         const int jc = max(j, 0);
 #pragma unroll
@@ -206,16 +222,16 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     };
     auto run2 = [&](Seg &s, int j) __attribute__((always_inline)) {
         // left -> right costs of this segment, recomputed from the checkpoint
-        uint32_t fst[NP], mv = 0x7fff7fffu;
+        uint32_t fst[NP], mv = UF ? 0xffffffffu : 0x7fff7fffu;
 #pragma unroll
-        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = pk_min(mv, fst[p]); }
-        uint32_t fmn = group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
+        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = UF ? pku_min(mv, fst[p]) : pk_min(mv, fst[p]); }
+        uint32_t fmn = UF ? group_min_splat_u<LPP>(mv) : group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
         uint32_t Lseg[SEG][NP];
 #pragma unroll
         for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = sgm_step<NP, LPP, PAD, !TONLY>(cost(s.c[u]), fst, fmn, pen, first, last, pad);
+            if (j * SEG + u < W1) fmn = path_step(cost(s.c[u]), fst, fmn);
 #pragma unroll
-            for (int p = 0; p < NP; p++) Lseg[u][p] = fst[p];
+            for (int p = 0; p < NP; p++) Lseg[u][p] = UF ? pk_sub(fst[p], P2x3) : fst[p];
         }
 #pragma unroll
         for (int u = SEG - 1; u >= 0; u--) {
@@ -224,10 +240,10 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 // (TONLY: cost() already ran on this column in the loop above and left C in place)
                 const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
                 const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
-                rmn = sgm_step<NP, LPP, PAD, !TONLY>(cu, rst, rmn, pen, first, last, pad);
+                rmn = path_step(cu, rst, rmn);
                 Pack<NP> S;
 #pragma unroll
-                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(pk_adds(rst[p], Lseg[u][p]), tu[p]);
+                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(UF ? pk_add(rst[p], Lseg[u][p]) : pk_adds(rst[p], Lseg[u][p]), tu[p]);
                 const uint32_t key = wta_min_key<NP, LPP>(S.v, d0);
                 *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
                 if (first) sK[grp * SEG + u] = key;
@@ -324,9 +340,16 @@ bool sgbm_launch_horizontal(const SgbmGeom &g, int B, const uint32_t *Cvol, cons
     return dispatch_variant(g.NPh, g.LPPh, g.Dp != g.D, [&](auto np, auto lpp, auto pd) {
         constexpr int NP = decltype(np)::value, LPP = decltype(lpp)::value;
         constexpr bool PAD = decltype(pd)::value;
+        const dim3 grid(cdiv(nrows, 64 / LPP));
+        if constexpr (!PAD) {
+            if (g.tonly && g.uform) {
+                hipLaunchKernelGGL((k_horizontal<NP, LPP, true, PAD, true>), grid, dim3(64), 0, s, g, nrows, Cvol, Tvol, Mvol, ckpt, wta, dsub);
+                return;
+            }
+        }
         if (g.tonly)
-            hipLaunchKernelGGL((k_horizontal<NP, LPP, true, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, Cvol, Tvol, Mvol, ckpt, wta, dsub);
+            hipLaunchKernelGGL((k_horizontal<NP, LPP, true, PAD, false>), grid, dim3(64), 0, s, g, nrows, Cvol, Tvol, Mvol, ckpt, wta, dsub);
         else
-            hipLaunchKernelGGL((k_horizontal<NP, LPP, false, PAD>), dim3(cdiv(nrows, 64 / LPP)), dim3(64), 0, s, g, nrows, Cvol, Tvol, Mvol, ckpt, wta, dsub);
+            hipLaunchKernelGGL((k_horizontal<NP, LPP, false, PAD, false>), grid, dim3(64), 0, s, g, nrows, Cvol, Tvol, Mvol, ckpt, wta, dsub);
     });
 }
