@@ -149,6 +149,46 @@ def test_sgbm_two_volume_path_bit_exact(gpu, O, monkeypatch):
     assert np.array_equal(got, dbg.disp)
 
 
+@pytest.mark.parametrize("W,H,D,b,batch", [(640, 360, 64, 5, 1), (384, 160, 96, 7, 5), (300, 90, 128, 9, 1), (200, 64, 32, 3, 5)])
+def test_sgbm_signed_path_only_form_bit_exact(gpu, O, monkeypatch, W, H, D, b, batch):
+    """Where no cost can saturate the scan kernels keep the path costs offset by P2 and run the recurrence in its unsigned
+    form; larger blocks use the signed form on the same path-only layout.  The signed form is forced here on shapes
+    that would take the unsigned one."""
+    monkeypatch.setenv("L3D_SGBM_UFORM", "0")
+    kw = _ref_ctor(D, b)
+    lb, rb = _pair(W, H, D, 21)
+    gl, gr = O.bgr2gray(lb), O.bgr2gray(rb)
+    m = _sgbm(**kw, max_batch=batch)
+    got = m.compute(gl, gr)
+    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), gl, gr)
+    assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C)
+    assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.T)
+    assert np.array_equal(got, dbg.disp)
+
+
+@pytest.mark.parametrize("D,b,extra", [(64, 5, {}), (96, 9, {}), (32, 3, dict(P1=900, P2=10000)), (64, 7, dict(P1=1, P2=2, preFilterCap=5)),
+                                        (128, 9, dict(preFilterCap=63, P1=7700, P2=7776))])
+def test_sgbm_unsigned_form_on_noise_images(gpu, O, D, b, extra):
+    """Uniform noise drives the pixel costs, hence the path costs, towards the top of their range -- where the unsigned
+    form of the recurrence (costs offset by P2, clamping subtractions) has to agree with the signed definition."""
+    W, H = 260, 70
+    rng = np.random.default_rng(D * 100 + b)
+    gl = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    gr = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    gl[:, ::7] = 255
+    gr[:, ::5] = 0
+    kw = _ref_ctor(D, b)
+    kw.update(extra)
+    for batch in (1, 5):
+        m = _sgbm(**kw, max_batch=batch)
+        got = m.compute(gl, gr)
+        dbg = O.sgbm_compute_debug(O.sgbm_params(**kw), gl, gr)
+        assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C)
+        assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.T)
+        assert np.array_equal(m.fetch_stage(2, 1, W, H)[0], dbg.raw)
+        assert np.array_equal(got, dbg.disp)
+
+
 def test_sgbm_known_answer_constant_shift(gpu):
     S = _S()
     left, right = S.shifted_pair(320, 96, 10)
