@@ -39,7 +39,7 @@ CONFIGS = {
     # what the reference's own constructor picks for a 640-px-wide eye (camera/single_usb_stereo_camera.py:239-282)
     "REFDEFAULT": (640, 360, 96, 7, True, 8000.0, 1.5),
 }
-DEFAULT_BATCH = {"C2": 256, "C3": 64, "C4": 32, "C5": 16, "REFDEFAULT": 128}
+DEFAULT_BATCH = {"C2": 256, "C3": 128, "C4": 32, "C5": 32, "REFDEFAULT": 128}
 C4_STREAMS = 8
 LASER_PLANE = np.array([0.0, 0.0, 1.0, -0.5])   # z = 0.5 m, the plane of the reference-generated golden vectors
 
@@ -178,7 +178,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times; the median run is reported")
-    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 64 for C3, 16 for C5; C4: per stream, 32)")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 128 for C3, 32 for C5; C4: per stream, 32)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--pipelines", type=int, default=2,
                     help="independent pipelines (matchers + buffers + streams) the steps alternate between, so that the tail of one "
