@@ -36,7 +36,7 @@ def test_reconstruct_from_depth_matches_reference_golden(O, golden):
     assert golden["empty_from_depth_shape"] == [0] and golden["empty_laser_line_shape"] == [0]
 
 
-def test_known_answers_from_survey(O):
+def test_known_answers_captured_from_the_reference(O):
     # values captured from the reference (K and plane of its calibration file)
     K = np.array([[209.025, 0, 159.5], [0, 209.72, 119.5], [0, 0, 1.0]])
     p = O.reconstruct_plane([[200.25, 100.5]], K, [0, 0, 1, -0.5], False)[0]
