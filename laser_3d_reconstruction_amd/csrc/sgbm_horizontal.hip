@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 const bool lo = uniq_f > 0;
                 const int16_t never = lo ? (int16_t)32767 : (int16_t)-32768;
                 if (e_h == 0) { rec[best - 1] = never; rec[best] = never; rec[best + 1] = never; }
+                asm volatile("" ::: "memory");   // the scan below reads the record through another type: keep it behind the three stores
                 const u32x4 *q = reinterpret_cast<const u32x4 *>(rec + e_h * 2 * WPL);
                 int m;
                 if (lo) {
