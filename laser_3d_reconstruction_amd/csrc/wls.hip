@@ -7,18 +7,22 @@
 // x < W - (minD + D) of the right view), width rw.  Planes in HBM, per handle:
 //   discL, discR [B][H][rw] f32   depth-discontinuity confidence of each view
 //   u1, u2       [B][H][rw] f32   confidence * disparity and confidence (smoothed in place)
-//   t1, t2       [B][rw][H] f32   the same two planes transposed
 //   cv           [B][H][rw] f32   vertical edge weights  -exp(-|I(y,x) - I(y+1,x)| / sigma)
-//   chT          [B][rw][H] f32   horizontal edge weights, transposed
+//   ch           [B][H][rw] f32   horizontal edge weights
 //   inter        [B][max(H,rw)][min] f32  normalised upper diagonal of the forward sweep
 //   conf         [B][H][W]  f32   confidence map (x255) in full-image coordinates
+//   (t1, t2, chT [B][rw][H] f32: u1, u2 and ch transposed, only when rw is not a multiple of 4)
 // The smoother's tridiagonal solves are sequential along a line and independent across lines, so
-// both passes run as "one thread per line, lines adjacent in memory": the vertical pass directly,
-// the horizontal pass on transposed planes (LDS tile transposes in between), which keeps every
-// load and store of the sweeps coalesced.
+// both passes run as one thread per line.  In the vertical pass adjacent lines are adjacent in
+// memory and every access of a wave is coalesced as it is (k_fgs_sweep).  In the horizontal pass a
+// line is a row of the plane: a wave moves 64 x 16 tiles of 64 rows as 16-byte pieces and turns
+// them through LDS (k_fgs_sweep_rows) -- no transposed copies of the planes, which cost two more
+// passes over both planes per iteration.  Sub-images whose width is not a multiple of 4 take the
+// older route: transpose, k_fgs_sweep, transpose back.
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -88,8 +92,8 @@ __global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ di
 __global__ void __launch_bounds__(256) k_wls_conf(const int16_t *__restrict__ dL, const int16_t *__restrict__ dR,
                                                   const uint8_t *__restrict__ guide, const float *__restrict__ lut, int W, int H, int lx0, int rx0,
                                                   int rw, int thresh, const float *__restrict__ discL, const float *__restrict__ discR,
-                                                  float *__restrict__ u1, float *__restrict__ u2, float *__restrict__ cv, float *__restrict__ chT,
-                                                  float *__restrict__ conf_full)
+                                                  float *__restrict__ u1, float *__restrict__ u2, float *__restrict__ cv, float *__restrict__ ch,
+                                                  float *__restrict__ chT, float *__restrict__ conf_full)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
@@ -112,7 +116,9 @@ __global__ void __launch_bounds__(256) k_wls_conf(const int16_t *__restrict__ dL
     conf_full[img + j] = c;
     const int g0 = guide[img + j];
     cv[sub + x] = (y < H - 1) ? lut[abs(g0 - (int)guide[img + W + j])] : 0.0f;
-    chT[((size_t)b * rw + x) * H + y] = (x < rw - 1) ? lut[abs(g0 - (int)guide[img + j + 1])] : 0.0f;
+    const float wh = (x < rw - 1) ? lut[abs(g0 - (int)guide[img + j + 1])] : 0.0f;
+    if (ch) ch[sub + x] = wh;                             // row sweeps on the planes as they lie
+    else chT[((size_t)b * rw + x) * H + y] = wh;          // sweeps on transposed planes
 }
 
 // out[b][c][r] = in[b][r][c] for two planes at once; 32x32 tiles through LDS
@@ -228,6 +234,164 @@ __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float 
         if (j0 - k >= 0) bwd(j0 - k, k);
 }
 
+// The same solves for lines whose elements are adjacent in memory (the rows of a row-major plane: the horizontal pass
+// without transposed copies of the planes), 64 lines to a block of one wave.  Per chunk of FGS_CHUNK elements the wave
+// moves a 64 x 16 tile of each operand between memory and registers in 16-byte pieces (a lane: a quarter of one line's
+// chunk, 16 lines per access, so an access covers 16 runs of 64 contiguous bytes), and the tile is turned through LDS so
+// that every thread ends up with the chunk of its own line.  What a thread computes on its line is the sequence of
+// k_fgs_sweep; only the route of the operands differs, so the results are identical.  n (the line length) is a multiple of 4.
+// `inter` keeps the layout of k_fgs_sweep ([element][line]): it is private to the sweep.
+constexpr int FGS_TS = FGS_CHUNK + 4;   // floats between the lines of a tile in LDS
+
+__global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
+                                                       float *__restrict__ inter, int n, int m, float lambda)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+    __shared__ __align__(16) float tile[3][64 * FGS_TS];
+    const int lane = threadIdx.x, l0 = blockIdx.x * 64, b = blockIdx.y;
+    const bool line_ok = l0 + lane < m;
+    const int line = min(l0 + lane, m - 1);                 // threads past the last line redo it and store nothing
+    const size_t pl = (size_t)b * n * m;
+    const BufRsrc r1 = make_rsrc(u1 + pl), r2 = make_rsrc(u2 + pl), rw = make_rsrc(w + pl), ri = make_rsrc(inter + pl);
+    const uint32_t ivoff = (uint32_t)line * 4u, irowb = (uint32_t)m * 4u;
+    // role in the tile moves: quarter cq of the chunk of lines cl, cl + 16, cl + 32, cl + 48
+    const int cq = lane & 3, cl = lane >> 2;
+    uint32_t rowoff[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        row_ok[r] = l0 + cl + 16 * r < m;
+        rowoff[r] = (uint32_t)min(l0 + cl + 16 * r, m - 1) * (uint32_t)n * 4u;
+    }
+    struct Quad { f32x4 v[4]; };
+    auto load_tile = [&](BufRsrc r, int i0) __attribute__((always_inline)) {
+        const uint32_t e = (uint32_t)min(i0 + 4 * cq, n - 4) * 4u;   // a piece past the line's end is loaded from its last piece, never used
+        Quad q;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, rowoff[k] + e, 0, 0));
+        return q;
+    };
+    auto store_tile = [&](BufRsrc r, int i0, const Quad &q) __attribute__((always_inline)) {
+        const bool piece_ok = i0 + 4 * cq < n;
+        const uint32_t e = (uint32_t)(i0 + 4 * cq) * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (piece_ok && row_ok[k]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, q.v[k]), r, rowoff[k] + e, 0, 0);
+    };
+    // registers of the tile moves <-> LDS <-> the chunk of this thread's line
+    auto put = [&](int t, const Quad &q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<f32x4 *>(&tile[t][(cl + 16 * k) * FGS_TS + 4 * cq]) = q.v[k];
+    };
+    auto take = [&](int t) __attribute__((always_inline)) {
+        Quad q;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q.v[k] = *reinterpret_cast<const f32x4 *>(&tile[t][(cl + 16 * k) * FGS_TS + 4 * cq]);
+        return q;
+    };
+    auto get_line = [&](int t, float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[t][lane * FGS_TS + 4 * k]);
+            x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+        }
+    };
+    auto put_line = [&](int t, const float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f32x4 v = {x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]};
+            *reinterpret_cast<f32x4 *>(&tile[t][lane * FGS_TS + 4 * k]) = v;
+        }
+    };
+    auto lds_wait = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    const int nchunks = (n + FGS_CHUNK - 1) / FGS_CHUNK;
+    float lower = 0.0f, prev_inter = 0.0f, p1 = 0.0f, p2 = 0.0f;
+    float xw[FGS_CHUNK], x1[FGS_CHUNK], x2[FGS_CHUNK];
+    // ---- forward elimination ----
+    {
+        Quad qw = load_tile(rw, 0), q1 = load_tile(r1, 0), q2 = load_tile(r2, 0);
+        for (int c = 0; c < nchunks; c++) {
+            const int i0 = c * FGS_CHUNK;
+            put(0, qw); put(1, q1); put(2, q2);
+            if (c + 1 < nchunks) { qw = load_tile(rw, i0 + FGS_CHUNK); q1 = load_tile(r1, i0 + FGS_CHUNK); q2 = load_tile(r2, i0 + FGS_CHUNK); }
+            lds_wait();
+            get_line(0, xw); get_line(1, x1); get_line(2, x2);
+            lds_wait();
+            auto fwd = [&](int k) __attribute__((always_inline)) {
+                const float upper = lambda * xw[k];
+                const float denom = (1.0f - lower - upper) - lower * prev_inter;
+                const float ci = upper / denom;
+                const float v1 = (x1[k] - lower * p1) / denom;
+                const float v2 = (x2[k] - lower * p2) / denom;
+                if (line_ok)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ci), ri, ivoff,
+                                                          __builtin_amdgcn_readfirstlane((uint32_t)(i0 + k) * irowb), 0);
+                x1[k] = v1; x2[k] = v2;
+                prev_inter = ci; p1 = v1; p2 = v2;
+                lower = upper;
+            };
+            if (i0 + FGS_CHUNK <= n) {   // no per-element tests outside the last, partial chunk
+#pragma unroll
+                for (int k = 0; k < FGS_CHUNK; k++) fwd(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < FGS_CHUNK; k++)
+                    if (i0 + k < n) fwd(k);
+            }
+            put_line(1, x1); put_line(2, x2);
+            lds_wait();
+            store_tile(r1, i0, take(1));
+            store_tile(r2, i0, take(2));
+            lds_wait();
+        }
+    }
+    // The back substitution reads what the elimination stored, most of it through other lanes of this wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- back substitution, from element n-2 down (element n-1 keeps its value) ----
+    {
+        auto load_inter = [&](int i0, float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < FGS_CHUNK; k++)
+                x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, ivoff, __builtin_amdgcn_readfirstlane((uint32_t)min(i0 + k, n - 1) * irowb), 0));
+        };
+        float nw[FGS_CHUNK];
+        int i0 = (nchunks - 1) * FGS_CHUNK;
+        Quad q1 = load_tile(r1, i0), q2 = load_tile(r2, i0);
+        load_inter(i0, xw);
+        for (int c = nchunks - 1; c >= 0; c--) {
+            i0 = c * FGS_CHUNK;
+            put(1, q1); put(2, q2);
+            if (c > 0) { q1 = load_tile(r1, i0 - FGS_CHUNK); q2 = load_tile(r2, i0 - FGS_CHUNK); load_inter(i0 - FGS_CHUNK, nw); }
+            lds_wait();
+            get_line(1, x1); get_line(2, x2);
+            lds_wait();
+            auto bwd = [&](int k) __attribute__((always_inline)) {
+                p1 = x1[k] - xw[k] * p1;
+                p2 = x2[k] - xw[k] * p2;
+                x1[k] = p1; x2[k] = p2;
+            };
+            if (i0 + FGS_CHUNK - 1 <= n - 2) {
+#pragma unroll
+                for (int k = FGS_CHUNK - 1; k >= 0; k--) bwd(k);
+            } else {
+#pragma unroll
+                for (int k = FGS_CHUNK - 1; k >= 0; k--)
+                    if (i0 + k <= n - 2) bwd(k);
+            }
+            put_line(1, x1); put_line(2, x2);
+            lds_wait();
+            store_tile(r1, i0, take(1));
+            store_tile(r2, i0, take(2));
+            lds_wait();
+#pragma unroll
+            for (int k = 0; k < FGS_CHUNK; k++) xw[k] = nw[k];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_wls_final(const float *__restrict__ u1, const float *__restrict__ u2, int W, int H, int lx0, int rw,
                                                    int fill, int16_t *__restrict__ out)
 {
@@ -264,7 +428,10 @@ struct l3d_wls {
     int lx0 = 0, rx0 = 0, rw = 0;
     hipStream_t stream = nullptr;
     float *lut = nullptr, *discL = nullptr, *discR = nullptr, *u1 = nullptr, *u2 = nullptr, *t1 = nullptr, *t2 = nullptr;
-    float *cv = nullptr, *chT = nullptr, *inter = nullptr, *conf = nullptr;
+    float *cv = nullptr, *ch = nullptr, *chT = nullptr, *inter = nullptr, *conf = nullptr;
+    // the horizontal pass sweeps the rows of the planes as they lie (k_fgs_sweep_rows) when the sub-image width is a
+    // multiple of 4; otherwise (or with L3D_WLS_TRANSPOSE=1) it runs on transposed copies of the planes
+    bool rows = false;
     int16_t *in_l = nullptr, *in_r = nullptr, *out = nullptr;
     uint8_t *in_g = nullptr;
 };
@@ -274,7 +441,7 @@ extern "C" void l3d_wls_destroy(l3d_wls *h)
     if (!h) return;
     DeviceGuard dg(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->lut, h->discL, h->discR, h->u1, h->u2, h->t1, h->t2, h->cv, h->chT, h->inter, h->conf, h->in_l, h->in_r, h->out, h->in_g};
+    void *bufs[] = {h->lut, h->discL, h->discR, h->u1, h->u2, h->t1, h->t2, h->cv, h->ch, h->chT, h->inter, h->conf, h->in_l, h->in_r, h->out, h->in_g};
     for (void *q : bufs)
         if (q) (void)hipFree(q);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -310,8 +477,17 @@ extern "C" int l3d_wls_create(const l3d_wls_params *p, int width, int height, in
         if (e == hipSuccess && bytes) e = hipMalloc(ptr, bytes);
     };
     alloc((void **)&h->lut, 256 * sizeof(float));
-    float **planes[] = {&h->discL, &h->discR, &h->u1, &h->u2, &h->t1, &h->t2, &h->cv, &h->chT, &h->inter};
+    h->rows = h->rw >= 4 && h->rw % 4 == 0;
+    if (const char *ov = std::getenv("L3D_WLS_TRANSPOSE"))
+        if (std::atoi(ov) != 0) h->rows = false;
+    float **planes[] = {&h->discL, &h->discR, &h->u1, &h->u2, &h->cv, &h->inter};
     for (float **pl : planes) alloc((void **)pl, sub * sizeof(float));
+    if (h->rows)
+        alloc((void **)&h->ch, sub * sizeof(float));
+    else {
+        float **tplanes[] = {&h->t1, &h->t2, &h->chT};
+        for (float **pl : tplanes) alloc((void **)pl, sub * sizeof(float));
+    }
     alloc((void **)&h->conf, B * px * sizeof(float));
     alloc((void **)&h->in_l, B * px * 2);
     alloc((void **)&h->in_r, B * px * 2);
@@ -346,14 +522,18 @@ static int wls_run(l3d_wls *h, const int16_t *dL, const int16_t *dR, const uint8
         hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dL, W, H, h->lx0, rw, r, h->p.disc_rolloff, h->discL);
         hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dR, W, H, h->rx0, rw, r, h->p.disc_rolloff, h->discR);
         hipLaunchKernelGGL(k_wls_conf, dim3(cdiv(rw, 256), H, B), dim3(256), 0, s, dL, dR, guide, h->lut, W, H, h->lx0, h->rx0, rw,
-                           h->p.lrc_thresh, h->discL, h->discR, h->u1, h->u2, h->cv, h->chT, h->conf);
+                           h->p.lrc_thresh, h->discL, h->discR, h->u1, h->u2, h->cv, h->ch, h->chT, h->conf);
         float lambda = (float)h->p.lambda;
         const dim3 tg_fwd(cdiv(rw, 32), cdiv(H, 32), B), tg_bwd(cdiv(H, 32), cdiv(rw, 32), B);
         for (int it = 0; it < h->p.fgs_iters; it++) {
-            // horizontal pass on the transposed planes: H lines of length rw
-            hipLaunchKernelGGL(k_transpose2, tg_fwd, dim3(256), 0, s, h->u1, h->u2, H, rw, h->t1, h->t2);
-            hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->t1, h->t2, h->chT, h->inter, rw, H, lambda);
-            hipLaunchKernelGGL(k_transpose2, tg_bwd, dim3(256), 0, s, h->t1, h->t2, rw, H, h->u1, h->u2);
+            // horizontal pass: H lines of length rw, on the planes as they lie or on transposed copies
+            if (h->rows)
+                hipLaunchKernelGGL(k_fgs_sweep_rows, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->u1, h->u2, h->ch, h->inter, rw, H, lambda);
+            else {
+                hipLaunchKernelGGL(k_transpose2, tg_fwd, dim3(256), 0, s, h->u1, h->u2, H, rw, h->t1, h->t2);
+                hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->t1, h->t2, h->chT, h->inter, rw, H, lambda);
+                hipLaunchKernelGGL(k_transpose2, tg_bwd, dim3(256), 0, s, h->t1, h->t2, rw, H, h->u1, h->u2);
+            }
             // vertical pass: rw lines of length H
             hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(rw, 64), B), dim3(64), 0, s, h->u1, h->u2, h->cv, h->inter, H, rw, lambda);
             lambda *= h->p.fgs_attenuation;

@@ -428,6 +428,36 @@ def test_wls_pipeline_bit_exact(gpu, O):
             wls.filter(dl, gl)
 
 
+@pytest.mark.parametrize("W,H,D,b,batch,force_transposed", [
+    (402, 97, 96, 7, 1, False),     # sub-image 306 wide: not a multiple of 4, the horizontal pass runs on transposed planes
+    (404, 97, 96, 7, 3, False),     # 308 wide: row sweeps on the planes as they lie, ragged chunk at the line's end, 97 lines
+    (336, 70, 32, 5, 2, False),     # 304 = 19 whole chunks
+    (404, 97, 96, 7, 3, True),      # the transposing route forced on a width that would take the row sweeps
+    (68, 130, 64, 5, 1, False),     # the narrowest sub-image: one piece of 4 columns
+])
+def test_wls_horizontal_pass_routes_equal_oracle(gpu, O, monkeypatch, W, H, D, b, batch, force_transposed):
+    """The smoother's horizontal pass has two routes (rows of the planes as they lie, through LDS tiles; or transposed
+    copies of the planes): both against the oracle, bit for bit, on widths and heights that leave ragged tiles."""
+    from laser_3d_reconstruction_amd import stereo
+
+    if force_transposed:
+        monkeypatch.setenv("L3D_WLS_TRANSPOSE", "1")
+    frames = [_pair(W, H, D, 30 + k) for k in range(batch)]
+    gl = np.stack([O.bgr2gray(f[0]) for f in frames])
+    gr = np.stack([O.bgr2gray(f[1]) for f in frames])
+    left = _sgbm(**_ref_ctor(D, b), max_batch=batch)
+    right = stereo.createRightMatcher(left)
+    wls = stereo.createDisparityWLSFilter(left)
+    wls.setLambda(8000.0)
+    wls.setSigmaColor(1.5)
+    dl, dr = left.compute(gl, gr), right.compute(gr, gl)
+    got = wls.filter(dl, gl, disparity_map_right=dr)
+    p = O.sgbm_params(**_ref_ctor(D, b))
+    for k in range(batch):
+        want = O.wls_filter(O.wls_params(p, 8000.0, 1.5), dl[k], dr[k], gl[k])
+        assert np.array_equal(got[k], want), f"frame {k}"
+
+
 def test_wls_constant_disparity_fixed_point(gpu):
     from laser_3d_reconstruction_amd import stereo
 
