@@ -17,7 +17,17 @@ namespace l3d {
 // ---------------------------------------------------------------------------------------------
 template <int NP, bool TONLY>
 struct SegLen {
-    static constexpr int value = ((NP <= 2 && !TONLY) || (NP == 4 && TONLY)) ? 8 : 4; // TONLY prefetches three operands per column
+    // TONLY prefetches three operands per column.  With 5 or 6 words a lane the 8-column segment fits the registers only
+    // when the next segment is requested late, half a segment at a time (LateFetch below).
+    static constexpr int value = ((NP <= 2 && !TONLY) || ((NP == 4 || NP == 5 || NP == 6) && TONLY)) ? 8 : 4;
+};
+
+// Whether the second sweep requests the next segment from inside the current one, in two halves (after the left -> right
+// costs of the current segment are rebuilt, and half way through its right -> left steps), instead of whole and ahead of it:
+// the operands of two whole segments at 13 registers a column do not fit beside the segment's left -> right costs.
+template <int NP, bool TONLY>
+struct LateFetch {
+    static constexpr bool value = TONLY && NP > 4 && SegLen<NP, TONLY>::value == 8;
 };
 
 // The aggregated cost of a column from the path volume: C = T - (min(P[d], P[d-1]+P1, P[d+1]+P1, minP+P2) - (minP+P2)),
@@ -74,6 +84,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                                                    uint32_t *__restrict__ ckpt, uint32_t *__restrict__ wta, int16_t *__restrict__ dsub)
 {
     constexpr int SEG = SegLen<NP, TONLY>::value;
+    constexpr bool LATE = LateFetch<NP, TONLY>::value;
     constexpr int RPW = 64 / LPP; // image rows per wave
     constexpr int CW = NP * LPP;  // u32 per volume column
     constexpr int D = 2 * CW;
@@ -181,7 +192,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // sweep has a third of the arithmetic of the second one per column: with whole segments fetched one segment
     // ahead it waited for memory.)
     {
-        constexpr int RING = 2 * SEG;
+        constexpr int RING = LATE ? SEG : 2 * SEG;
         constexpr int BURST = 4;   // measured 1 / 2 / 4 / 8: 3.61 / 3.59 / 3.58 / 3.58 ms at 640x360, 64 disparities, 256 frames
         ColIn<NP, TONLY> ring[RING];
 #pragma unroll
@@ -216,16 +227,22 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // UF: the left -> right costs enter the sum with 3 * P2 taken off, which is the offset of the three summands together:
     // (R' + (L' - 3 P2)) + T' = R + L + T, the last addition saturating as in the definition (the first cannot)
     const uint32_t P2x3 = pk_splat(3 * g.P2);
-    auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
+    // columns u0 .. u1-1 of segment j (and its checkpoint with the first of them)
+    auto fetch2_part = [&](Seg &s, int j, auto u0c, auto u1c) __attribute__((always_inline)) {
+        constexpr int u0 = decltype(u0c)::value, u1 = decltype(u1c)::value;
         const int jc = max(j, 0);
 #pragma unroll
-        for (int u = 0; u < SEG; u++) {
+        for (int u = u0; u < u1; u++) {
             s.c[u] = fetch(jc * SEG + u);
             if constexpr (!TONLY) s.t[u] = ldT(jc * SEG + u);
         }
-        s.ck = buf_load<NP>(Kr, koff, (uint32_t)jc * (uint32_t)col_bytes);
+        if (u0 == 0) s.ck = buf_load<NP>(Kr, koff, (uint32_t)jc * (uint32_t)col_bytes);
     };
-    auto run2 = [&](Seg &s, int j) __attribute__((always_inline)) {
+    auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
+        fetch2_part(s, j, std::integral_constant<int, 0>{}, std::integral_constant<int, SEG>{});
+    };
+    // `nxt`, `jn`: the segment to request from inside this one (LATE)
+    auto run2 = [&](Seg &s, int j, Seg &nxt, int jn) __attribute__((always_inline)) {
         // left -> right costs of this segment, recomputed from the checkpoint
         uint32_t fst[NP], mv = UF ? 0xffffffffu : 0x7fff7fffu;
 #pragma unroll
@@ -238,9 +255,13 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
             for (int p = 0; p < NP; p++) Lseg[u][p] = UF ? pk_sub(fst[p], P2x3) : fst[p];
         }
+        if constexpr (LATE) fetch2_part(nxt, jn, std::integral_constant<int, 0>{}, std::integral_constant<int, SEG / 2>{});
 #pragma unroll
         for (int u = SEG - 1; u >= 0; u--) {
             const int xc = j * SEG + u;
+            if constexpr (LATE) {
+                if (u == SEG / 2 - 1) fetch2_part(nxt, jn, std::integral_constant<int, SEG / 2>{}, std::integral_constant<int, SEG>{});
+            }
             if (xc < W1) {
                 // (TONLY: cost() already ran on this column in the loop above and left C in place)
                 const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
@@ -326,12 +347,12 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     int j = nseg - 1;
     for (; j >= 1; j -= 2) {
         // two segments per turn with the buffers swapping roles: no copy of the segment in flight
-        fetch2(B, j - 1);
-        run2(A, j);
-        fetch2(A, j - 2);
-        run2(B, j - 1);
+        if constexpr (!LATE) fetch2(B, j - 1);
+        run2(A, j, B, j - 1);
+        if constexpr (!LATE) fetch2(A, j - 2);
+        run2(B, j - 1, A, j - 2);
     }
-    if (j == 0) run2(A, 0);
+    if (j == 0) run2(A, 0, B, -1);
 }
 
 } // namespace l3d
