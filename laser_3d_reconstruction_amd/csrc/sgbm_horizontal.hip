@@ -17,9 +17,9 @@ namespace l3d {
 // ---------------------------------------------------------------------------------------------
 template <int NP, bool TONLY>
 struct SegLen {
-    // TONLY prefetches three operands per column.  With 5 or 6 words a lane the 8-column segment fits the registers only
-    // when the next segment is requested late, half a segment at a time (LateFetch below).
-    static constexpr int value = ((NP <= 2 && !TONLY) || ((NP == 4 || NP == 5 || NP == 6) && TONLY)) ? 8 : 4;
+    // TONLY prefetches three operands per column.  The longer segments fit the registers only when the next segment is
+    // requested late, a few columns at a time (LateFetch below): 16 columns with 4 words a lane, 8 with 5 or 6.
+    static constexpr int value = (NP == 4 && TONLY) ? 16 : ((NP <= 2 && !TONLY) || ((NP == 5 || NP == 6) && TONLY)) ? 8 : 4;
 };
 
 // Whether the second sweep requests the next segment from inside the current one, in two halves (after the left -> right
@@ -27,7 +27,7 @@ struct SegLen {
 // the operands of two whole segments at 13 registers a column do not fit beside the segment's left -> right costs.
 template <int NP, bool TONLY>
 struct LateFetch {
-    static constexpr bool value = TONLY && NP > 4 && SegLen<NP, TONLY>::value == 8;
+    static constexpr bool value = TONLY && ((NP > 4 && SegLen<NP, TONLY>::value == 8) || SegLen<NP, TONLY>::value == 16);
 };
 
 // The aggregated cost of a column from the path volume: C = T - (min(P[d], P[d-1]+P1, P[d+1]+P1, minP+P2) - (minP+P2)),
@@ -93,14 +93,16 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     // sub-pixel fit of the segment's RPW * SEG (row, column) pairs, LPI lanes to a pair.  (Per column, on the lanes that
     // hold the sums, the uniqueness test costs a table read, two packed operations per word and a reduction over the
     // group in which every lane computes the same value: 25 instructions per column against 8 here.)
-    __shared__ __align__(16) int16_t sS[8 + RPW * SEG * REC];
-    __shared__ uint32_t sK[RPW * SEG];
+    // the per-segment step takes at most 8 columns at a time: a 16-column segment runs it twice
+    constexpr int SSEG = SEG < 8 ? SEG : 8;
+    __shared__ __align__(16) int16_t sS[8 + RPW * SSEG * REC];
+    __shared__ uint32_t sK[RPW * SSEG];
     // results of OSEG segments per row, so that they leave as 64-byte (keys) and 32-byte (disparities) runs:
     // 16- and 8-byte stores scattered over rows reached HBM as partial lines (+40 % write traffic)
     constexpr int OSEG = 16 / SEG > 0 ? 16 / SEG : 1, OCOL = OSEG * SEG;
     __shared__ uint32_t oK[RPW * OCOL];
     __shared__ int16_t oD[RPW * OCOL];
-    constexpr int ITEMS = RPW * SEG, LPI = 64 / ITEMS;   // pairs per segment, lanes per pair
+    constexpr int ITEMS = RPW * SSEG, LPI = 64 / ITEMS;  // pairs per step, lanes per pair
     constexpr int WPL = CW / LPI;                        // words of a pair's summed costs that one lane scans
     static_assert(LPI >= 1 && LPI <= 4 && LPI * ITEMS == 64 && WPL % 4 == 0, "per-segment step: lane split");
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     };
     // role of this lane in the per-segment step: part e_h of column e_u of row e_grp
     const int e_item = tid / LPI, e_h = tid % LPI;
-    const int e_u = e_item % SEG, e_grp = e_item / SEG;
+    const int e_u = e_item % SSEG, e_grp = e_item / SSEG;
     const bool e_on = e_h == 0 && row0 + e_grp < nrows_total;
     const int uniq_f = 100 - g.uniq;
     uint32_t *wblk = wta + (size_t)row0 * W1;
@@ -241,44 +243,12 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
     auto fetch2 = [&](Seg &s, int j) __attribute__((always_inline)) {
         fetch2_part(s, j, std::integral_constant<int, 0>{}, std::integral_constant<int, SEG>{});
     };
-    // `nxt`, `jn`: the segment to request from inside this one (LATE)
-    auto run2 = [&](Seg &s, int j, Seg &nxt, int jn) __attribute__((always_inline)) {
-        // left -> right costs of this segment, recomputed from the checkpoint
-        uint32_t fst[NP], mv = UF ? 0xffffffffu : 0x7fff7fffu;
-#pragma unroll
-        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = UF ? pku_min(mv, fst[p]) : pk_min(mv, fst[p]); }
-        uint32_t fmn = UF ? group_min_splat_u<LPP>(mv) : group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
-        uint32_t Lseg[SEG][NP];
-#pragma unroll
-        for (int u = 0; u < SEG; u++) {
-            if (j * SEG + u < W1) fmn = path_step(cost(s.c[u]), fst, fmn);
-#pragma unroll
-            for (int p = 0; p < NP; p++) Lseg[u][p] = UF ? pk_sub(fst[p], P2x3) : fst[p];
-        }
-        if constexpr (LATE) fetch2_part(nxt, jn, std::integral_constant<int, 0>{}, std::integral_constant<int, SEG / 2>{});
-#pragma unroll
-        for (int u = SEG - 1; u >= 0; u--) {
-            const int xc = j * SEG + u;
-            if constexpr (LATE) {
-                if (u == SEG / 2 - 1) fetch2_part(nxt, jn, std::integral_constant<int, SEG / 2>{}, std::integral_constant<int, SEG>{});
-            }
-            if (xc < W1) {
-                // (TONLY: cost() already ran on this column in the loop above and left C in place)
-                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
-                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
-                rmn = path_step(cu, rst, rmn);
-                Pack<NP> S;
-#pragma unroll
-                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(UF ? pk_add(rst[p], Lseg[u][p]) : pk_adds(rst[p], Lseg[u][p]), tu[p]);
-                const uint32_t key = wta_min_key<NP, LPP>(S.v, d0);
-                *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SEG + u) * REC + d0) = S;
-                if (first) sK[grp * SEG + u] = key;
-            }
-        }
-        // per-segment step: uniqueness test and parabola fit per (row, column)
+    // The step that runs once per (at most 8) finished columns of a segment: uniqueness test and parabola fit per (row, column).
+    // half: which 8 columns of a 16-column segment.
+    auto seg_step = [&](int j, int half) __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {
-            const int xc = j * SEG + e_u;
+            const int xc = j * SEG + half * SSEG + e_u;
             const uint32_t key = sK[e_item];
             const int best = xc < W1 ? (int)(key & 0xffffu) : 0;   // columns past the row's end hold nothing: stay inside the record
             const int sc = (int)(key >> 16) - 32768;
@@ -324,10 +294,58 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 reject = (int)(short)(m & 0xffff) * uniq_f < sc * 100;
             }
             if (e_on && xc < W1) {
-                const int slot = e_grp * OCOL + (j % OSEG) * SEG + e_u;
+                const int slot = e_grp * OCOL + (j % OSEG) * SEG + half * SSEG + e_u;
                 oK[slot] = reject ? 0xffffffffu : key;
                 oD[slot] = (int16_t)(reject ? 0 : subpixel_disp(g, best, sm, sc, sp));
             }
+        }
+        asm volatile("" ::: "memory");
+    };
+    // `nxt`, `jn`: the segment to request from inside this one (LATE)
+    auto run2 = [&](Seg &s, int j, Seg &nxt, int jn) __attribute__((always_inline)) {
+        // left -> right costs of this segment, recomputed from the checkpoint
+        uint32_t fst[NP], mv = UF ? 0xffffffffu : 0x7fff7fffu;
+#pragma unroll
+        for (int p = 0; p < NP; p++) { fst[p] = s.ck.v[p]; mv = UF ? pku_min(mv, fst[p]) : pk_min(mv, fst[p]); }
+        uint32_t fmn = UF ? group_min_splat_u<LPP>(mv) : group_min_splat<LPP>(mv); // the previous minimum is the minimum of the previous state
+        uint32_t Lseg[SEG][NP];
+#pragma unroll
+        for (int u = 0; u < SEG; u++) {
+            if (j * SEG + u < W1) fmn = path_step(cost(s.c[u]), fst, fmn);
+#pragma unroll
+            for (int p = 0; p < NP; p++) Lseg[u][p] = UF ? pk_sub(fst[p], P2x3) : fst[p];
+        }
+        // LATE: the next segment is requested four columns at a time while the registers of this one free up
+        auto part = [&](auto k) __attribute__((always_inline)) {
+            constexpr int u0 = 4 * decltype(k)::value;
+            fetch2_part(nxt, jn, std::integral_constant<int, u0>{}, std::integral_constant<int, u0 + 4>{});
+        };
+        if constexpr (LATE && SEG == 8) part(std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int u = SEG - 1; u >= 0; u--) {
+            const int xc = j * SEG + u;
+            if constexpr (LATE && SEG == 8) {
+                if (u == 3) part(std::integral_constant<int, 1>{});
+            }
+            if constexpr (LATE && SEG == 16) {
+                if (u == 11) part(std::integral_constant<int, 0>{});
+                if (u == 8) part(std::integral_constant<int, 1>{});
+                if (u == 5) part(std::integral_constant<int, 2>{});
+                if (u == 2) part(std::integral_constant<int, 3>{});
+            }
+            if (xc < W1) {
+                // (TONLY: cost() already ran on this column in the loop above and left C in place)
+                const uint32_t(&cu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].p.v; else return s.c[u].c.v; }();
+                const uint32_t(&tu)[NP] = [&]() -> const uint32_t(&)[NP] { if constexpr (TONLY) return s.c[u].t.v; else return s.t[u].v; }();
+                rmn = path_step(cu, rst, rmn);
+                Pack<NP> S;
+#pragma unroll
+                for (int p = 0; p < NP; p++) S.v[p] = pk_adds(UF ? pk_add(rst[p], Lseg[u][p]) : pk_adds(rst[p], Lseg[u][p]), tu[p]);
+                const uint32_t key = wta_min_key<NP, LPP>(S.v, d0);
+                *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SSEG + u % SSEG) * REC + d0) = S;
+                if (first) sK[grp * SSEG + u % SSEG] = key;
+            }
+            if (u % SSEG == 0) seg_step(j, u / SSEG);
         }
         if (j % OSEG == 0) {
             // the columns j*SEG .. j*SEG+OCOL-1 of every row are complete
