@@ -9,7 +9,7 @@ for pass in "$@"; do
   n=$((n+1))
   out=$ROOT/gpurun_out/pmc_${tag}_$n
   rm -rf $out
-  timeout -s KILL 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out -o vm -- python3 $ROOT/scripts/dev_sweep.py > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out -o vm -- python3 $ROOT/scripts/dev_sweep.py $SWEEP_ARGS > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections
