@@ -557,6 +557,20 @@ __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__r
     const int W = g.W, W1 = g.W1, bd = blockDim.x, tid = threadIdx.x;
     const uint32_t *w = wta + (size_t)row * W1;
     const int16_t *ds = dsub + (size_t)row * W1;
+    if (g.disp12MaxDiff > g.D + 1) {
+        // The winner of a right-image column and a pixel's own disparity differ by at most D + 1, so the check cannot
+        // fire (the matchers behind the disparity filter are configured this way: disp12MaxDiff = 10^6): the row is
+        // the accepted sub-pixel disparities in place, without the second map and its dependent loads.
+        int16_t *o = raw + (size_t)row * W;
+        for (int x = tid; x < W; x += bd) {
+            const bool in = x >= g.minX1 && x < g.maxX1;
+            const int xc = in ? x - g.minX1 : 0;
+            const uint32_t kw = w[xc];
+            const int d = ds[xc];
+            o[x] = (int16_t)((in && kw != 0xffffffffu) ? d : g.invalid16);
+        }
+        return;
+    }
     for (int x = tid; x < W; x += bd) key2[x] = 0xffffffffu;
     __syncthreads();
     for (int base = 0; base < W1; base += LR_ILP * bd) {
