@@ -5,8 +5,8 @@
 // filter2D difference stencils, and the per-pixel Python loop that calls np.linalg.eig on the
 // 2x2 Hessian of every pixel brighter than the threshold.
 //
-// A streaming pass marks the 64x16 pixel tiles that hold a pixel above the threshold (the laser covers a few
-// percent of a frame) and a second kernel lists them; one fused kernel then works per listed tile:
+// A streaming pass flags the 64x16 pixel tiles that hold a pixel above the threshold (the laser covers a few
+// percent of a frame); one fused kernel, a fixed grid whose blocks share the tiles out by stride, then works per flagged tile:
 //   gray (u8) of the tile -> exact per-pixel brightness test (exit when none passes) -> gray tile with
 //   halo staged in LDS as float -> separable Gaussian through LDS -> stencils, closed-form 2x2
 //   symmetric eigen-decomposition in double, acceptance test -> per-row ballot compaction into
@@ -22,6 +22,7 @@
 // the tile, then a per-row pass over the row's tiles).
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -129,9 +130,11 @@ __device__ __forceinline__ bool steger2_point(float dx, float dy, float dxx, flo
 template <int VAR>
 __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ taps, float2 *__restrict__ cells, int *__restrict__ cell_counts,
-                                                     const int *__restrict__ tiles)
+                                                     int *__restrict__ tiles)
 {
     extern __shared__ float sm[];
+    __shared__ int s_list[256];
+    __shared__ int s_n, s_wcnt[4];
     constexpr int HB = VAR == VAR_FAST ? 1 : 2;         // halo of the blurred tile that the derivative stencils reach
     const int R = a.R, ks = 2 * R + 1;
     const int GW = TW + 2 * HB + 2 * R, GH = TH + 2 * HB + 2 * R; // gray tile incl. halo
@@ -144,12 +147,37 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     uint8_t *gt = reinterpret_cast<uint8_t *>(xrange + 2);   // [GH][GW] gray values, kept as bytes (a quarter of the LDS: 8 blocks per CU instead of 5)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int ti = tiles ? blockIdx.x : 0; ti < (tiles ? tiles[0] : 1); ti += gridDim.x) {
-    // the tile: an entry of the list of tiles with bright pixels (tiles[0] entries, in no particular order), or
-    // (without a list) the block's own
+    // With tile flags (tiles[1 + t] != 0: tile t holds a bright pixel) the grid is G blocks per image: every block of an
+    // image reads that image's flags, 256 at a time, ranks the flagged tiles by ballots and prefix sums, and works on those
+    // whose rank is its own number modulo G -- the flagged tiles of an image are shared out evenly whatever their pattern,
+    // without a list in memory, a kernel to build it, or additions to a shared counter.  The compaction kernel, which runs
+    // after this one, puts the flags back to zero.  Without flags the grid is (ntx, nty, batch) and the block works on
+    // its own tile.
+    const int nt = a.ntx * a.nty;                                   // tiles of an image
+    const int G = tiles ? (int)gridDim.x / (a.ntiles / nt) : 1;
+    const int img_b = tiles ? (int)blockIdx.x / G : 0, g = tiles ? (int)blockIdx.x % G : 0;
+    int rank_base = 0;
+    for (int c0 = 0; c0 < (tiles ? nt : 1); c0 += 256) {
+    if (tiles) {
+        __syncthreads();       // the previous chunk's list is used up
+        if (tid == 0) s_n = 0;
+        const int i = c0 + tid;
+        const bool on = i < nt && tiles[1 + (size_t)img_b * nt + i] != 0;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) s_wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int pre = rank_base;
+        for (int w = 0; w < wv; w++) pre += s_wcnt[w];
+        const int r = pre + __popcll(m & ((1ull << lane) - 1ull));
+        if (on && r % G == g) s_list[atomicAdd(&s_n, 1)] = img_b * nt + i;
+        rank_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    const int n_here = tiles ? s_n : 1;
+    for (int ti = 0; ti < n_here; ti++) {
     int txi = blockIdx.x, tyi = blockIdx.y, b = blockIdx.z;
     if (tiles) {
-        const int t = tiles[1 + a.ntiles + ti];
+        const int t = s_list[ti];
         txi = t % a.ntx;
         tyi = (t / a.ntx) % a.nty;
         b = t / (a.ntx * a.nty);
@@ -378,45 +406,59 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
         }
     }
     } // tiles
+    } // chunks of flags
 }
 
 // Most tiles hold no bright pixel, and starting a 256-thread block per tile only to find that out took more than
-// half of the extraction time.  A streaming pass marks the tiles that have one (a thread tests four pixels of a row:
-// for the hybrid variant the mask, otherwise gray > threshold; the tile kernel repeats the exact test per pixel),
-// a second kernel turns the marks into a list, and the tile kernel walks that list.
+// half of the extraction time.  A streaming pass flags the tiles that have one (a thread tests sixteen pixels of a row:
+// for the hybrid variant the mask, otherwise gray > threshold; the tile kernel repeats the exact test per pixel), and
+// the blocks of the tile kernel share the flagged tiles of an image out among themselves.  (A list of the flagged tiles,
+// built by a kernel in between, cost a launch and 12 us of additions to one counter; a call is a chain of dependent
+// launches of a few tens of microseconds each, and every launch fewer is worth about 8 us.)
+// MARK_PX pixels of a row per thread (a divisor of the tile width, so they share a tile); the threads are numbered over
+// (image, row, group of MARK_PX) without gaps, whatever the row length.
+constexpr int MARK_PX = 16;
 __global__ void __launch_bounds__(256) k_steger_mark(StegerArgs a, const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                     int *__restrict__ tiles)
+                                                     int *__restrict__ tiles, int groups_per_row, int total)
 {
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
-    if (x >= a.rw) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int row = t / groups_per_row, x = (t - row * groups_per_row) * MARK_PX;
+    const int b = row / a.rh, y = row - b * a.rh;
     const uint8_t *im = img + (size_t)b * a.W * a.H * a.channels;
     bool bright = false;
-    if (!mask && a.channels == 3 && x + 4 <= a.rw) {
-        // the four pixels as three (unaligned) words instead of twelve bytes
-        uint32_t w[3];
-        __builtin_memcpy(w, im + ((size_t)(y + a.y0) * a.W + (x + a.x0)) * 3, 12);
+    if (!mask && a.channels == 3 && x + MARK_PX <= a.rw) {
+        // the pixels as (unaligned) words instead of single bytes: 48 bytes in flight per thread
+        uint32_t w[3 * MARK_PX / 4];
+        __builtin_memcpy(w, im + ((size_t)(y + a.y0) * a.W + (x + a.x0)) * 3, 3 * MARK_PX);
         auto byte = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < MARK_PX; k++)
             bright |= (int)((byte(3 * k + 2) * 9798u + byte(3 * k + 1) * 19235u + byte(3 * k) * 3735u + (1u << 14)) >> 15) > a.thr;
-    } else {
+    } else if (!mask && a.channels == 1 && x + MARK_PX <= a.rw) {
+        uint32_t w[MARK_PX / 4];
+        __builtin_memcpy(w, im + (size_t)(y + a.y0) * a.W + (x + a.x0), MARK_PX);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MARK_PX; k++) bright |= (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu) > a.thr;
+    } else {
+        for (int k = 0; k < MARK_PX; k++) {
             if (x + k < a.rw) {
                 if (mask) bright |= mask[(size_t)b * a.W * a.H + (size_t)y * a.W + x + k] != 0;
                 else bright |= gray_at(im, a, x + k, y) > a.thr;
             }
         }
     }
-    if (bright) tiles[1 + ((size_t)b * a.nty + y / TH) * a.ntx + x / TW] = 1;   // 4 | TW: the four pixels share a tile
+    if (bright) tiles[1 + ((size_t)b * a.nty + y / TH) * a.ntx + x / TW] = 1;   // MARK_PX | TW: the pixels share a tile
 }
 
-// (Appending to the list from the marking pass itself -- the first thread to flag a tile takes a slot -- doubled that
-// pass's time: ten thousand atomic additions to one counter, against 12 us for this kernel.)
-__global__ void __launch_bounds__(256) k_steger_list(int ntiles, int *__restrict__ tiles)
+// Clears the tile flags and the per-cell counts: what a call expects to find at zero.  The kernels of a call leave them at
+// zero again (the compaction kernel clears both), so this runs only before a handle's first call, after a call that failed
+// half way, and once per device for the static work array.
+__global__ void __launch_bounds__(256) k_steger_clear(int *__restrict__ tiles, size_t n_tiles, int *__restrict__ cell_counts, size_t n_cells)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < ntiles && tiles[1 + t]) tiles[1 + ntiles + atomicAdd(&tiles[0], 1)] = t;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < n_tiles; k += stride) tiles[k] = 0;
+    for (size_t k = i; k < n_cells; k += stride) cell_counts[k] = 0;
 }
 
 // per-row variants: the best candidate over the tiles of a row (first tile on ties) becomes the row's only point
@@ -443,18 +485,22 @@ __global__ void __launch_bounds__(256) k_steger_rowbest(int nrows_total, int rh,
 // one block per image: exclusive scan of the cell counts in raster order; every thread then copies the few
 // points of its own cell (a cell holds the accepted pixels of 64 columns of one row: a handful at most on a
 // laser line) to where the scan says they go
-__global__ void __launch_bounds__(1024) k_steger_compact(int ncells, const float2 *__restrict__ cells, const int *__restrict__ cell_counts,
-                                                         float2 *__restrict__ out, int capacity, int *__restrict__ counts)
+// (the counts it has read are left at zero for the next call)
+__global__ void __launch_bounds__(1024) k_steger_compact(int ncells, const float2 *__restrict__ cells, int *__restrict__ cell_counts,
+                                                         float2 *__restrict__ out, int capacity, int *__restrict__ counts,
+                                                         int *__restrict__ tiles, int tiles_per_image)
 {
+    for (int i = threadIdx.x; i < tiles_per_image; i += 1024) tiles[1 + (size_t)blockIdx.x * tiles_per_image + i] = 0;   // the image's tile flags
     __shared__ int wsum[2][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int *cc = cell_counts + (size_t)b * ncells;
+    int *cc = cell_counts + (size_t)b * ncells;
     const float2 *cs = cells + (size_t)b * ncells * TW;
     float2 *o = out + (size_t)b * capacity;
     int carry = 0; // points before this chunk: the same in every thread
     for (int base = 0, it = 0; base < ncells; base += 1024, it ^= 1) {
         const int i = base + tid;
         const int v = i < ncells ? cc[i] : 0;
+        if (v) cc[i] = 0;
         int s = v; // inclusive scan inside the wave
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
@@ -491,7 +537,13 @@ struct l3d_steger {
     float *taps = nullptr;
     float2 *cells = nullptr;
     int *cell_counts = nullptr;
-    int *tile_list = nullptr;   // [0] = number of tiles that hold a bright pixel, then [max tiles] flags, then the list
+    int *tile_list = nullptr;   // [1 + t]: tile t holds a bright pixel ([0] unused)
+    // The kernels of a call leave the tile flags and the per-cell counts at zero (the compaction kernel clears both),
+    // which is what the next call expects.
+    // `dirty` says that this may not hold (before the first call, and after a call that failed half way): the next
+    // call then clears both arrays first.  The static work array has one such flag per device instead.
+    bool dirty_own = true;
+    bool *dirty = nullptr;
     size_t max_tiles = 0;
     // staging for the host entry point
     uint8_t *in = nullptr;
@@ -621,18 +673,30 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
     const size_t lds = ((size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB) + (size_t)(TH + 2 * HB) * (TW + 2 * HB) + (2 * R + 1) + 3) * sizeof(float) +
                        (size_t)(TH + 2 * HB + 2 * R) * (TW + 2 * HB + 2 * R);   // float tiles, taps and flags, then the gray tile in bytes
     a.ntiles = a.ntx * a.nty * B;
-    // tiles with bright pixels -> list; cells of all other tiles are empty
+    // tiles with bright pixels get a flag; cells of all other tiles are empty
     L3D_REQUIRE((size_t)a.ntiles <= h->max_tiles, "steger: %d tiles exceed the %zu the work buffers hold", a.ntiles, h->max_tiles);
     L3D_REQUIRE((size_t)B * a.rh * a.ntx <= h->cells_capacity, "steger: %zu cells exceed the %zu the work buffers hold", (size_t)B * a.rh * a.ntx,
                 h->cells_capacity);
-    L3D_HIP_CHECK(hipMemsetAsync(h->tile_list, 0, (size_t)(1 + a.ntiles) * sizeof(int), s));   // list length and the flags
-    L3D_HIP_CHECK(hipMemsetAsync(h->cell_counts, 0, (size_t)B * a.rh * a.ntx * sizeof(int), s));
-    hipLaunchKernelGGL(k_steger_mark, dim3(cdiv(cdiv(a.rw, 4), 256), a.rh, B), dim3(256), 0, s, a, d_img, variant == VAR_HYBRID ? d_mask : nullptr,
-                       h->tile_list);
-    hipLaunchKernelGGL(k_steger_list, dim3(cdiv(a.ntiles, 256)), dim3(256), 0, s, a.ntiles, h->tile_list);
-    // the list's length stays on the device: a fixed grid of about two resident rounds walks it (measured at 58,880
-    // tiles of which 10,000 are listed: 2048 blocks 104 us, 4096 90 us, 16384 89 us -- and 4 / 4 / 14 us when none is)
-    const dim3 grid(std::min(a.ntiles, 4096));
+    bool &dirty = h->dirty ? *h->dirty : h->dirty_own;
+    if (dirty) {
+        const size_t n_tiles = 1 + h->max_tiles, n_cells = h->cells_capacity;
+        hipLaunchKernelGGL(k_steger_clear, dim3((unsigned)std::min<size_t>((std::max(n_tiles, n_cells) + 1023) / 1024, 2048)), dim3(256), 0, s,
+                           h->tile_list, n_tiles, h->cell_counts, n_cells);
+    }
+    dirty = true;
+    {
+        const int groups = cdiv(a.rw, MARK_PX);
+        const long long total = (long long)groups * a.rh * B;
+        L3D_REQUIRE(total < (1ll << 31), "steger: %lld pixel groups exceed the marking pass's index range", total);
+        hipLaunchKernelGGL(k_steger_mark, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, d_img, variant == VAR_HYBRID ? d_mask : nullptr,
+                           h->tile_list, groups, (int)total);
+    }
+    // G blocks per image share its flagged tiles out among themselves: about two resident rounds of blocks in all, and
+    // no more blocks per image than it has tiles
+    // (measured at 256 frames of 640x360 with a laser line, 10,000 of 58,880 tiles flagged: 2048 blocks 151 us per call,
+    // 3072 143, 4096 140, 6144 151, 8192 150; without a laser 38 ... 49 us)
+    const int G = std::max(1, std::min(std::min(a.ntx * a.nty, 64), 4096 / B));
+    const dim3 grid((unsigned)(B * G));
     switch (variant) {
     case VAR_FAST: hipLaunchKernelGGL(k_steger_tile<VAR_FAST>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
     case VAR_IMPROVED: hipLaunchKernelGGL(k_steger_tile<VAR_IMPROVED>, grid, dim3(256), lds, s, a, d_img, d_mask, h->taps, h->cells, h->cell_counts, h->tile_list); break;
@@ -643,8 +707,9 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
         hipLaunchKernelGGL(k_steger_rowbest, dim3(cdiv(B * a.rh, 256)), dim3(256), 0, s, B * a.rh, a.rh, a.ntx, h->cells, h->cell_counts);
     const int ncells = a.rh * a.ntx;
     hipLaunchKernelGGL(k_steger_compact, dim3(B), dim3(1024), 0, s, ncells, h->cells, h->cell_counts, (float2 *)d_xy,
-                       capacity, d_counts);
+                       capacity, d_counts, h->tile_list, a.ntx * a.nty);
     L3D_HIP_CHECK(hipGetLastError());
+    dirty = false;   // every kernel of the call is enqueued: flags and counts are at zero again when they have run
     return L3D_OK;
 }
 
@@ -754,6 +819,13 @@ extern "C" int l3d_steger_extract_device_static(double sigma, int brightness_thr
     v.cell_counts = reinterpret_cast<int *>(base + kStaticTapsBytes + kStaticListBytes);
     v.cells = reinterpret_cast<float2 *>(base + kStaticTapsBytes + kStaticListBytes + kStaticCountBytes);
     v.max_tiles = kStaticCells;
+    static bool static_dirty[kMaxDevices];
+    static bool static_dirty_init = false;
+    if (!static_dirty_init) {
+        for (bool &d : static_dirty) d = true;
+        static_dirty_init = true;
+    }
+    v.dirty = &static_dirty[device < kMaxDevices ? device : 0];
     v.max_cells = (size_t)height * cdiv(width, TW);
     v.cells_capacity = kStaticCells;
     hipStream_t s = (hipStream_t)stream;
