@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs in the build container after scripts/gpu_profile.sh <cfg>: copies the summaries merged into
-# gpurun_out/profile_<cfg>/ to profiles/ under this round's names and derives the traffic tables.
+# gpurun_out/profile_<cfg>/ to profiles/ under the names of the given tag and derives the traffic tables.
 # usage: scripts/collect_profile.sh <tag> <cfg> <batch per launch>
 tag=$1; cfg=$2; batch=$3
 src=gpurun_out/profile_$cfg
