@@ -10,6 +10,11 @@ import numpy as np
 from .. import _native as N
 
 
+def _as_tuples(pts: np.ndarray) -> List[Tuple[float, float]]:
+    """(N,2) array -> list of (x, y) Python floats (the float32 values widened exactly)."""
+    return list(map(tuple, np.asarray(pts, np.float64).tolist()))
+
+
 class SimpleLaserExtractor:
     """HSV + brightness threshold extractor (core/laser_extractor.py:14-100):
     ``extract_centerline(image BGR uint8) -> [(x, y), ...]``, one intensity-weighted
@@ -74,7 +79,7 @@ class SimpleLaserExtractor:
         return (pts, masks) if want_masks else pts
 
     def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
-        return [(float(x), float(y)) for x, y in self.extract_points(image)]
+        return _as_tuples(self.extract_points(image))
 
     def extract_device(self, image):
         """torch uint8 CUDA tensor (H,W,3) -> list of (x, y); runs on torch's current stream."""
@@ -90,7 +95,7 @@ class SimpleLaserExtractor:
         N.check(N.lib.l3d_simple_extract_device(hd, C.c_void_p(image.data_ptr()), w, h, lo, hi,
                                                 int(self.brightness_threshold), C.c_double(float(self.min_area)),
                                                 N.ptr(xy), C.byref(n), stream), "l3d_simple_extract_device")
-        return [(float(x), float(y)) for x, y in xy[: n.value]]
+        return _as_tuples(xy[: n.value])
 
 
 class FastStegerExtractor:
@@ -169,7 +174,7 @@ class FastStegerExtractor:
         pts = self.extract_points(image, roi)[0]
         if self.verbose:
             print(f"  image {image.shape[1]}x{image.shape[0]}: {len(pts)} centre points")
-        return [(float(x), float(y)) for x, y in pts]
+        return _as_tuples(pts)
 
     def extract_batch(self, images: List[np.ndarray]) -> List[List[Tuple[float, float]]]:
         """One launch for the whole list when the images share a shape."""
@@ -180,7 +185,7 @@ class FastStegerExtractor:
             res = self.extract_points(np.stack(images))
         else:
             res = [self.extract_points(im)[0] for im in images]
-        return [[(float(x), float(y)) for x, y in p] for p in res]
+        return [_as_tuples(p) for p in res]
 
     def extract_device(self, images, capacity: int, roi=None):
         """torch uint8 CUDA tensor (B,H,W,3) or (B,H,W) -> (xy (B,capacity,2) float32, counts (B,) int32) on device."""
