@@ -30,6 +30,7 @@ namespace l3d {
 
 constexpr int TW = 64, TH = 16;
 constexpr int MAX_TAPS = 65;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct StegerArgs {
     int W, H;             // full image size
@@ -80,8 +81,12 @@ __device__ __forceinline__ bool steger_point(float dx, float dy, float dxx, floa
         const double v1x = b, v1y = lam - a;
         const double v2x = lam - c, v2y = b;
         const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y;
-        if (n1 >= n2) { const double s = 1.0 / sqrt(n1); nx = v1x * s; ny = v1y * s; }
-        else { const double s = 1.0 / sqrt(n2); nx = v2x * s; ny = v2y * s; }
+        // the eigenvector with the larger norm, chosen before the square root and the division so that a wave
+        // whose lanes disagree runs them once
+        const bool first = n1 >= n2;
+        const double s = 1.0 / sqrt(first ? n1 : n2);
+        nx = (first ? v1x : v2x) * s;
+        ny = (first ? v1y : v2y) * s;
     }
     const double den = nx * nx * a + 2.0 * nx * ny * b + ny * ny * c;
     if (!(fabs(den) > 1e-10)) return false;
@@ -108,8 +113,10 @@ __device__ __forceinline__ bool steger2_point(float dx, float dy, float dxx, flo
         lam = (m >= 0.0) ? m + rr : m - rr;
         const double v1x = b, v1y = lam - a, v2x = lam - c, v2y = b;
         const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y;
-        if (n1 >= n2) { const double s = 1.0 / sqrt(n1); nx = v1x * s; ny = v1y * s; }
-        else { const double s = 1.0 / sqrt(n2); nx = v2x * s; ny = v2y * s; }
+        const bool first = n1 >= n2;
+        const double s = 1.0 / sqrt(first ? n1 : n2);
+        nx = (first ? v1x : v2x) * s;
+        ny = (first ? v1y : v2y) * s;
     }
     lamf = (float)lam;
     const float nxf = (float)nx, nyf = (float)ny;
@@ -154,8 +161,12 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     // after this one, puts the flags back to zero.  Without flags the grid is (ntx, nty, batch) and the block works on
     // its own tile.
     const int nt = a.ntx * a.nty;                                   // tiles of an image
-    const int G = tiles ? (int)gridDim.x / (a.ntiles / nt) : 1;
-    const int img_b = tiles ? (int)blockIdx.x / G : 0, g = tiles ? (int)blockIdx.x % G : 0;
+    const int n_img = a.ntiles / nt;
+    const int G = tiles ? (int)gridDim.x / n_img : 1;
+    // Block numbers run over the images first, then over g: blocks start in the order of their numbers, and the blocks with
+    // a low g never have the smaller share of their image's tiles, so the longer blocks start first and the launch does not
+    // end in a tail of them (140 -> 122 us per 256 frames against g running first).
+    const int img_b = tiles ? (int)blockIdx.x % n_img : 0, g = tiles ? (int)blockIdx.x / n_img : 0;
     int rank_base = 0;
     for (int c0 = 0; c0 < (tiles ? nt : 1); c0 += 256) {
     if (tiles) {
@@ -245,17 +256,23 @@ __global__ void __launch_bounds__(256) k_steger_tile(StegerArgs a, const uint8_t
     __syncthreads();
     // row pass: taps accumulated left to right.  Outputs are dealt to the threads in raster order of the nb columns
     // (all lanes busy whatever nb is); a thread steps from one of its outputs to the next without dividing again.
+    // A thread computes the same column of two adjacent rows (GH is even) as the two halves of packed single-precision
+    // operations: one multiplication and one addition per tap for both, each half rounded as the scalar operation is.
     {
         const int q256 = 256 / nb, r256 = 256 - q256 * nb;
-        int gy = tid / nb, bxl = tid - gy * nb;
-        for (; gy < GH; ) {
-            const uint8_t *src = gt + gy * GW + b0 + bxl;
-            float s = 0.0f;
+        int gp = tid / nb, bxl = tid - gp * nb;
+        for (; gp < GH / 2; ) {
+            const uint8_t *src0 = gt + 2 * gp * GW + b0 + bxl, *src1 = src0 + GW;
+            f32x2 s = {0.0f, 0.0f};
 #pragma unroll 5
-            for (int k = 0; k < ks; k++) s = s + tp[k] * (float)src[k];   // (unrolled: the LDS reads of five taps go out together)
-            hrow[gy * BW + b0 + bxl] = s;
-            gy += q256; bxl += r256;
-            if (bxl >= nb) { bxl -= nb; gy++; }
+            for (int k = 0; k < ks; k++) {   // (unrolled: the LDS reads of five taps go out together)
+                const f32x2 v = {(float)src0[k], (float)src1[k]};
+                s = s + tp[k] * v;
+            }
+            hrow[2 * gp * BW + b0 + bxl] = s.x;
+            hrow[(2 * gp + 1) * BW + b0 + bxl] = s.y;
+            gp += q256; bxl += r256;
+            if (bxl >= nb) { bxl -= nb; gp++; }
         }
     }
     __syncthreads();
