@@ -235,13 +235,17 @@ __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float 
 }
 
 // The same solves for lines whose elements are adjacent in memory (the rows of a row-major plane: the horizontal pass
-// without transposed copies of the planes), 64 lines to a block of one wave.  Per chunk of FGS_CHUNK elements the wave
-// moves a 64 x 16 tile of each operand between memory and registers in 16-byte pieces (a lane: a quarter of one line's
-// chunk, 16 lines per access, so an access covers 16 runs of 64 contiguous bytes), and the tile is turned through LDS so
-// that every thread ends up with the chunk of its own line.  What a thread computes on its line is the sequence of
+// without transposed copies of the planes), 64 lines to a block of one wave.  Per chunk of FGS_RCHUNK elements the wave
+// moves a 64 x 32 tile of each operand between memory and registers in 16-byte pieces (a lane: an eighth of one line's
+// chunk, 8 lines per access, so an access covers 8 runs of 128 contiguous bytes: whole cache lines -- with 16-element
+// chunks a wave touched 64-byte halves of lines and the sweep moved 6.8 GB where the column sweep moves 4.8), and the
+// tile is turned through LDS so that every thread ends up with the chunk of its own line.  What a thread computes on its line is the sequence of
 // k_fgs_sweep; only the route of the operands differs, so the results are identical.  n (the line length) is a multiple of 4.
 // `inter` keeps the layout of k_fgs_sweep ([element][line]): it is private to the sweep.
-constexpr int FGS_TS = FGS_CHUNK + 4;   // floats between the lines of a tile in LDS
+constexpr int FGS_RCHUNK = 32;            // elements of a line per chunk: 128 contiguous bytes a line and access
+constexpr int FGS_PPL = FGS_RCHUNK / 4;   // 16-byte pieces of a line's chunk = lanes that share a line in a tile move
+constexpr int FGS_LPA = 64 / FGS_PPL;     // lines per access of the wave
+constexpr int FGS_TS = FGS_RCHUNK + 4;    // floats between the lines of a tile in LDS
 
 __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
                                                        float *__restrict__ inter, int n, int m, float lambda)
@@ -255,67 +259,67 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
     const size_t pl = (size_t)b * n * m;
     const BufRsrc r1 = make_rsrc(u1 + pl), r2 = make_rsrc(u2 + pl), rw = make_rsrc(w + pl), ri = make_rsrc(inter + pl);
     const uint32_t ivoff = (uint32_t)line * 4u, irowb = (uint32_t)m * 4u;
-    // role in the tile moves: quarter cq of the chunk of lines cl, cl + 16, cl + 32, cl + 48
-    const int cq = lane & 3, cl = lane >> 2;
-    uint32_t rowoff[4];
-    bool row_ok[4];
+    // role in the tile moves: piece cq of the chunk of lines cl, cl + FGS_LPA, cl + 2 * FGS_LPA, ...
+    const int cq = lane % FGS_PPL, cl = lane / FGS_PPL;
+    uint32_t rowoff[FGS_PPL];
+    bool row_ok[FGS_PPL];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        row_ok[r] = l0 + cl + 16 * r < m;
-        rowoff[r] = (uint32_t)min(l0 + cl + 16 * r, m - 1) * (uint32_t)n * 4u;
+    for (int r = 0; r < FGS_PPL; r++) {
+        row_ok[r] = l0 + cl + FGS_LPA * r < m;
+        rowoff[r] = (uint32_t)min(l0 + cl + FGS_LPA * r, m - 1) * (uint32_t)n * 4u;
     }
-    struct Quad { f32x4 v[4]; };
+    struct Quad { f32x4 v[FGS_PPL]; };
     auto load_tile = [&](BufRsrc r, int i0) __attribute__((always_inline)) {
         const uint32_t e = (uint32_t)min(i0 + 4 * cq, n - 4) * 4u;   // a piece past the line's end is loaded from its last piece, never used
         Quad q;
 #pragma unroll
-        for (int k = 0; k < 4; k++) q.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, rowoff[k] + e, 0, 0));
+        for (int k = 0; k < FGS_PPL; k++) q.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, rowoff[k] + e, 0, 0));
         return q;
     };
     auto store_tile = [&](BufRsrc r, int i0, const Quad &q) __attribute__((always_inline)) {
         const bool piece_ok = i0 + 4 * cq < n;
         const uint32_t e = (uint32_t)(i0 + 4 * cq) * 4u;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < FGS_PPL; k++)
             if (piece_ok && row_ok[k]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, q.v[k]), r, rowoff[k] + e, 0, 0);
     };
     // registers of the tile moves <-> LDS <-> the chunk of this thread's line
     auto put = [&](int t, const Quad &q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) *reinterpret_cast<f32x4 *>(&tile[t][(cl + 16 * k) * FGS_TS + 4 * cq]) = q.v[k];
+        for (int k = 0; k < FGS_PPL; k++) *reinterpret_cast<f32x4 *>(&tile[t][(cl + FGS_LPA * k) * FGS_TS + 4 * cq]) = q.v[k];
     };
     auto take = [&](int t) __attribute__((always_inline)) {
         Quad q;
 #pragma unroll
-        for (int k = 0; k < 4; k++) q.v[k] = *reinterpret_cast<const f32x4 *>(&tile[t][(cl + 16 * k) * FGS_TS + 4 * cq]);
+        for (int k = 0; k < FGS_PPL; k++) q.v[k] = *reinterpret_cast<const f32x4 *>(&tile[t][(cl + FGS_LPA * k) * FGS_TS + 4 * cq]);
         return q;
     };
-    auto get_line = [&](int t, float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+    auto get_line = [&](int t, float (&x)[FGS_RCHUNK]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < FGS_PPL; k++) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[t][lane * FGS_TS + 4 * k]);
             x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
         }
     };
-    auto put_line = [&](int t, const float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+    auto put_line = [&](int t, const float (&x)[FGS_RCHUNK]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < FGS_PPL; k++) {
             const f32x4 v = {x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]};
             *reinterpret_cast<f32x4 *>(&tile[t][lane * FGS_TS + 4 * k]) = v;
         }
     };
     auto lds_wait = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
-    const int nchunks = (n + FGS_CHUNK - 1) / FGS_CHUNK;
+    const int nchunks = (n + FGS_RCHUNK - 1) / FGS_RCHUNK;
     float lower = 0.0f, prev_inter = 0.0f, p1 = 0.0f, p2 = 0.0f;
-    float xw[FGS_CHUNK], x1[FGS_CHUNK], x2[FGS_CHUNK];
+    float xw[FGS_RCHUNK], x1[FGS_RCHUNK], x2[FGS_RCHUNK];
     // ---- forward elimination ----
     {
         Quad qw = load_tile(rw, 0), q1 = load_tile(r1, 0), q2 = load_tile(r2, 0);
         for (int c = 0; c < nchunks; c++) {
-            const int i0 = c * FGS_CHUNK;
+            const int i0 = c * FGS_RCHUNK;
             put(0, qw); put(1, q1); put(2, q2);
-            if (c + 1 < nchunks) { qw = load_tile(rw, i0 + FGS_CHUNK); q1 = load_tile(r1, i0 + FGS_CHUNK); q2 = load_tile(r2, i0 + FGS_CHUNK); }
+            if (c + 1 < nchunks) { qw = load_tile(rw, i0 + FGS_RCHUNK); q1 = load_tile(r1, i0 + FGS_RCHUNK); q2 = load_tile(r2, i0 + FGS_RCHUNK); }
             lds_wait();
             get_line(0, xw); get_line(1, x1); get_line(2, x2);
             lds_wait();
@@ -332,12 +336,12 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
                 prev_inter = ci; p1 = v1; p2 = v2;
                 lower = upper;
             };
-            if (i0 + FGS_CHUNK <= n) {   // no per-element tests outside the last, partial chunk
+            if (i0 + FGS_RCHUNK <= n) {   // no per-element tests outside the last, partial chunk
 #pragma unroll
-                for (int k = 0; k < FGS_CHUNK; k++) fwd(k);
+                for (int k = 0; k < FGS_RCHUNK; k++) fwd(k);
             } else {
 #pragma unroll
-                for (int k = 0; k < FGS_CHUNK; k++)
+                for (int k = 0; k < FGS_RCHUNK; k++)
                     if (i0 + k < n) fwd(k);
             }
             put_line(1, x1); put_line(2, x2);
@@ -352,19 +356,19 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- back substitution, from element n-2 down (element n-1 keeps its value) ----
     {
-        auto load_inter = [&](int i0, float (&x)[FGS_CHUNK]) __attribute__((always_inline)) {
+        auto load_inter = [&](int i0, float (&x)[FGS_RCHUNK]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < FGS_CHUNK; k++)
+            for (int k = 0; k < FGS_RCHUNK; k++)
                 x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, ivoff, __builtin_amdgcn_readfirstlane((uint32_t)min(i0 + k, n - 1) * irowb), 0));
         };
-        float nw[FGS_CHUNK];
-        int i0 = (nchunks - 1) * FGS_CHUNK;
+        float nw[FGS_RCHUNK];
+        int i0 = (nchunks - 1) * FGS_RCHUNK;
         Quad q1 = load_tile(r1, i0), q2 = load_tile(r2, i0);
         load_inter(i0, xw);
         for (int c = nchunks - 1; c >= 0; c--) {
-            i0 = c * FGS_CHUNK;
+            i0 = c * FGS_RCHUNK;
             put(1, q1); put(2, q2);
-            if (c > 0) { q1 = load_tile(r1, i0 - FGS_CHUNK); q2 = load_tile(r2, i0 - FGS_CHUNK); load_inter(i0 - FGS_CHUNK, nw); }
+            if (c > 0) { q1 = load_tile(r1, i0 - FGS_RCHUNK); q2 = load_tile(r2, i0 - FGS_RCHUNK); load_inter(i0 - FGS_RCHUNK, nw); }
             lds_wait();
             get_line(1, x1); get_line(2, x2);
             lds_wait();
@@ -373,12 +377,12 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
                 p2 = x2[k] - xw[k] * p2;
                 x1[k] = p1; x2[k] = p2;
             };
-            if (i0 + FGS_CHUNK - 1 <= n - 2) {
+            if (i0 + FGS_RCHUNK - 1 <= n - 2) {
 #pragma unroll
-                for (int k = FGS_CHUNK - 1; k >= 0; k--) bwd(k);
+                for (int k = FGS_RCHUNK - 1; k >= 0; k--) bwd(k);
             } else {
 #pragma unroll
-                for (int k = FGS_CHUNK - 1; k >= 0; k--)
+                for (int k = FGS_RCHUNK - 1; k >= 0; k--)
                     if (i0 + k <= n - 2) bwd(k);
             }
             put_line(1, x1); put_line(2, x2);
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
             store_tile(r2, i0, take(2));
             lds_wait();
 #pragma unroll
-            for (int k = 0; k < FGS_CHUNK; k++) xw[k] = nw[k];
+            for (int k = 0; k < FGS_RCHUNK; k++) xw[k] = nw[k];
         }
     }
 }
