@@ -616,12 +616,8 @@ __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__r
             ka[i] = key2[ina[i] ? _x : 0];
             kb[i] = key2[inb[i] ? x_ : 0];
         }
-        uint32_t wa[LR_ILP], wb[LR_ILP];
-#pragma unroll
-        for (int i = 0; i < LR_ILP; i++) {
-            wa[i] = w[ka[i] == 0xffffffffu ? 0 : 0xffff - (int)(ka[i] & 0xffffu)];
-            wb[i] = w[kb[i] == 0xffffffffu ? 0 : 0xffff - (int)(kb[i] & 0xffffu)];
-        }
+        // The disparity of the left pixel that won a right-image column follows from the two columns (it was recorded at
+        // column x2 = its own column - its disparity), so its key is not read again: one dependent load fewer per pixel.
 #pragma unroll
         for (int i = 0; i < LR_ILP; i++) {
             const int x = base + i * bd + tid;
@@ -631,8 +627,8 @@ __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__r
                 val = d1[i];
                 if (val != g.invalid16) {
                     const int _d = val >> 4, d_ = (val + 15) >> 4;
-                    const int va = ka[i] == 0xffffffffu ? g.invalid16 : (int)(wa[i] & 0xffffu) + g.minD;
-                    const int vb = kb[i] == 0xffffffffu ? g.invalid16 : (int)(wb[i] & 0xffffu) + g.minD;
+                    const int va = ka[i] == 0xffffffffu ? g.invalid16 : (0xffff - (int)(ka[i] & 0xffffu)) + g.minX1 - (x - _d);
+                    const int vb = kb[i] == 0xffffffffu ? g.invalid16 : (0xffff - (int)(kb[i] & 0xffffu)) + g.minX1 - (x - d_);
                     const bool c1 = ina[i] && va >= g.minD && abs(va - _d) > g.disp12MaxDiff;
                     const bool c2 = inb[i] && vb >= g.minD && abs(vb - d_) > g.disp12MaxDiff;
                     if (c1 && c2) val = g.invalid16;
