@@ -41,20 +41,8 @@ namespace l3d {
 // ---------------------------------------------------------------------------------------------
 // K1: x-Sobel prefilter + Birchfield-Tomasi half-pixel min/max for both images
 // ---------------------------------------------------------------------------------------------
-// The six per-pixel quantities of one image at (x, y) from the prefiltered values of x-1, x, x+1
-struct PixRec {
-    int gc, glo, ghi, rc, rlo, rhi;
-};
-__device__ __forceinline__ PixRec pix_rec(int x, int W, int gm, int gc, int gp, int rm, int rc, int rp)
-{
-    const int gl = x > 0 ? (gc + gm) / 2 : gc, gr = x < W - 1 ? (gc + gp) / 2 : gc;
-    const int rl = x > 0 ? (rc + rm) / 2 : rc, rr = x < W - 1 ? (rc + rp) / 2 : rc;
-    PixRec o;
-    o.gc = gc; o.glo = min(gc, min(gl, gr)); o.ghi = max(gc, max(gl, gr));
-    o.rc = rc; o.rlo = min(rc, min(rl, rr)); o.rhi = max(rc, max(rl, rr));
-    return o;
-}
-
+// Per pixel and image six quantities: the clipped x-Sobel value gc, the minimum glo and maximum ghi of gc and the two
+// half-pixel means (gc + g[x-1]) / 2, (gc + g[x+1]) / 2, and the same three (rc, rlo, rhi) for the intensity.
 // One wave per strip of PF_ROWS image rows x 62 groups of 4 pixels of one image (blockIdx.z = 2 * frame + side); a
 // lane owns one group of 4 consecutive pixels and walks down the strip with a window of three rows in registers.
 // CH = 1: gray input; CH = 3: BGR input, converted on the way in with the fixed-point weights of
@@ -85,22 +73,33 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
     const bool have = gq >= 0 && xq < W;                    // the group holds image pixels
     const bool whole = have && xq + 4 <= W;
     const bool owner = have && lane >= 1 && lane <= PF_GROUPS;
-    // gray values of this lane's four pixels in image row y (clamped: the Sobel kernel replicates the first / last row)
-    auto gray_word = [&](int y) -> uint32_t {
-        const uint8_t *row = img + (size_t)min(max(y, 0), H - 1) * W * CH;
+    // The bytes of the lane's four pixels in the PF_ROWS + 2 image rows of the strip's window (rows clamped: the Sobel
+    // kernel replicates the first / last row) are requested together, before the first of them is used: per row a wave
+    // is one short chain of dependent steps, and with a single row in flight it spent its time waiting for memory.
+    constexpr int NW = CH == 3 ? 3 : 1;
+    auto row_ptr = [&](int r) { return img + (size_t)min(max(ys - 1 + r, 0), H - 1) * W * CH; };   // r: row of the window
+    uint32_t raw[PF_ROWS + 2][NW];
+#pragma unroll
+    for (int r = 0; r < PF_ROWS + 2; r++) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) raw[r][k] = 0;
+        if (whole) __builtin_memcpy(raw[r], row_ptr(r) + (size_t)xq * CH, 4 * NW);
+    }
+    // gray values of this lane's four pixels in window row r
+    auto gray_word = [&](int r) -> uint32_t {
         uint32_t v = 0;
         if (whole) {
             if (CH == 3) {
-                uint32_t w[3];
-                __builtin_memcpy(w, row + (size_t)xq * 3, 12);
+                const uint32_t *w = raw[r];
                 const uint32_t p0 = ((w[0] >> 16 & 0xffu) * 9798u + (w[0] >> 8 & 0xffu) * 19235u + (w[0] & 0xffu) * 3735u + (1u << 14)) >> 15;
-                const uint32_t p1 = ((w[1] >> 8 & 0xffu) * 9798u + (w[1] & 0xffu) * 19235u + (w[0] >> 24) * 3735u + (1u << 14)) >> 15;
-                const uint32_t p2 = ((w[2] & 0xffu) * 9798u + (w[1] >> 24) * 19235u + (w[1] >> 16 & 0xffu) * 3735u + (1u << 14)) >> 15;
-                const uint32_t p3 = ((w[2] >> 24) * 9798u + (w[2] >> 16 & 0xffu) * 19235u + (w[2] >> 8 & 0xffu) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p1 = ((w[NW - 2] >> 8 & 0xffu) * 9798u + (w[NW - 2] & 0xffu) * 19235u + (w[0] >> 24) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p2 = ((w[NW - 1] & 0xffu) * 9798u + (w[NW - 2] >> 24) * 19235u + (w[NW - 2] >> 16 & 0xffu) * 3735u + (1u << 14)) >> 15;
+                const uint32_t p3 = ((w[NW - 1] >> 24) * 9798u + (w[NW - 1] >> 16 & 0xffu) * 19235u + (w[NW - 1] >> 8 & 0xffu) * 3735u + (1u << 14)) >> 15;
                 v = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
             } else
-                __builtin_memcpy(&v, row + xq, 4);
+                v = raw[r][0];
         } else if (have) {
+            const uint8_t *row = row_ptr(r);
 #pragma unroll
             for (int k = 0; k < 4; k++) {                   // the image's last, partial group: pixel by pixel (pixels past the edge are never used)
                 const uint8_t *px = row + (size_t)min(xq + k, W - 1) * CH;
@@ -112,60 +111,97 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
     };
     // window of three rows: [row][0..2] = gray words of the groups gq-1, gq, gq+1
     uint32_t wn[3], w0[3], ws[3];
-    auto fill = [&](uint32_t (&w)[3], int y) __attribute__((always_inline)) {
-        w[1] = gray_word(y);
+    auto fill = [&](uint32_t (&w)[3], int r) __attribute__((always_inline)) {
+        w[1] = gray_word(r);
         w[0] = __shfl_up(w[1], 1);
         w[2] = __shfl_down(w[1], 1);
     };
-    fill(w0, ys - 1);
-    fill(ws, ys);
+    fill(w0, 0);
+    fill(ws, 1);
     const size_t img_off = (size_t)b * plane;
     const int yend = min(ys + PF_ROWS, H);
-    for (int y = ys; y < yend; y++) {
+    // per pair of the six pixels xq - 1 .. xq + 4: 0xffff in the halves whose pixel is not an image border column
+    uint32_t inner[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+        const int xa = xq - 1 + 2 * jj, xb = xa + 1;
+        inner[jj] = ((xa <= 0 || xa >= W - 1) ? 0u : 0xffffu) | ((xb <= 0 || xb >= W - 1) ? 0u : 0xffff0000u);
+    }
+    const uint32_t fz = pk_splat(ftzero), nfz = pk_splat(-ftzero);
+#pragma unroll
+    for (int ry = 0; ry < PF_ROWS; ry++) {
+        const int y = ys + ry;
+        if (y >= yend) continue;                            // whole wave
 #pragma unroll
         for (int k = 0; k < 3; k++) { wn[k] = w0[k]; w0[k] = ws[k]; }
-        fill(ws, y + 1);
+        fill(ws, ry + 2);
         if (!owner) continue;
-        auto byte = [](const uint32_t (&w)[3], int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu); };
-        int g[6], rw[6];
+        // Pairs of adjacent pixels as the 16-bit halves of a word: the window's bytes are widened by byte permutes and the
+        // arithmetic is packed (all values lie in 0 .. 1020, nothing saturates).  Byte i of a window row is pixel xq - 4 + i.
+        auto even_pair = [](const uint32_t (&w)[3], int m) -> uint32_t {   // (byte 2m, byte 2m + 1), m = 1 .. 4
+            return m == 1 ? __builtin_amdgcn_perm(w[0], w[0], 0x0c030c02u) : m == 2 ? __builtin_amdgcn_perm(w[1], w[1], 0x0c010c00u)
+                 : m == 3 ? __builtin_amdgcn_perm(w[1], w[1], 0x0c030c02u) : __builtin_amdgcn_perm(w[2], w[2], 0x0c010c00u);
+        };
+        // clipped x-Sobel value and intensity of pixels xq - 1 .. xq + 4 as three pairs; image columns 0 and W-1 (and
+        // beyond) read ftzero in both channels
+        uint32_t G[3], R[3];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {     // pixel xq - 1 + k sits at byte k + 3
-            const int x = xq - 1 + k;
-            int v = (byte(w0, k + 4) - byte(w0, k + 2)) * 2 + byte(wn, k + 4) - byte(wn, k + 2) + byte(ws, k + 4) - byte(ws, k + 2);
-            v = min(max(v, -ftzero), ftzero) + ftzero;
-            const bool border = x <= 0 || x >= W - 1;   // image columns 0 and W-1 (and beyond): both channels read ftzero
-            g[k] = border ? ftzero : v;
-            rw[k] = border ? ftzero : byte(w0, k + 3);
+        for (int jj = 0; jj < 3; jj++) {
+            const uint32_t d0 = pk_sub(even_pair(w0, jj + 2), even_pair(w0, jj + 1));
+            const uint32_t dn = pk_sub(even_pair(wn, jj + 2), even_pair(wn, jj + 1));
+            const uint32_t dsv = pk_sub(even_pair(ws, jj + 2), even_pair(ws, jj + 1));
+            uint32_t v = pk_add(pk_add(d0, d0), pk_add(dn, dsv));
+            v = pk_add(pk_min(pk_max(v, nfz), fz), fz);
+            G[jj] = (v & inner[jj]) | (fz & ~inner[jj]);
         }
-        PixRec rec[4];
+        R[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x0c040c03u);   // bytes 3, 4
+        R[1] = __builtin_amdgcn_perm(w0[1], w0[1], 0x0c020c01u);   // bytes 5, 6
+        R[2] = __builtin_amdgcn_perm(w0[2], w0[1], 0x0c040c03u);   // bytes 7, 8
 #pragma unroll
-        for (int i = 0; i < 4; i++) rec[i] = pix_rec(min(xq + i, W - 1), W, g[i], g[i + 1], g[i + 2], rw[i], rw[i + 1], rw[i + 2]);
+        for (int jj = 0; jj < 3; jj++) R[jj] = (R[jj] & inner[jj]) | (fz & ~inner[jj]);
+        // value, half-pixel minimum and maximum of the lane's four pixels as two pairs per quantity.  (The reference takes
+        // the value itself in place of the half-pixel mean at the image's first and last column; with ftzero in those
+        // columns and beyond them the mean is that value anyway.)
+        const v2u one = {1, 1};
+        auto rec_pair = [&](uint32_t m, uint32_t c, uint32_t pn, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+            const uint32_t l = as_u32u(as_v2u(pk_add(c, m)) >> one), r = as_u32u(as_v2u(pk_add(c, pn)) >> one);
+            lo = pku_min(c, pku_min(l, r));
+            hi = pku_max(c, pku_max(l, r));
+        };
+        uint32_t gc[2], glo[2], ghi[2], rc[2], rlo[2], rhi[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            gc[q] = __builtin_amdgcn_alignbit(G[q + 1], G[q], 16);
+            rc[q] = __builtin_amdgcn_alignbit(R[q + 1], R[q], 16);
+            rec_pair(G[q], gc[q], G[q + 1], glo[q], ghi[q]);
+            rec_pair(R[q], rc[q], R[q + 1], rlo[q], rhi[q]);
+        }
         if (side == 0) {
             uint2 *o = lrec + img_off + (size_t)y * W + xq;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (xq + i < W)
-                    o[i] = make_uint2((uint32_t)(rec[i].gc | (rec[i].glo << 8) | (rec[i].ghi << 16)), (uint32_t)(rec[i].rc | (rec[i].rlo << 8) | (rec[i].rhi << 16)));
+            for (int i = 0; i < 4; i++) {
+                const int q = i >> 1;
+                const uint32_t s1 = (i & 1) ? 0x0c0c0602u : 0x0c0c0400u, s2 = (i & 1) ? 0x0c060100u : 0x0c040100u;
+                const uint32_t wg = __builtin_amdgcn_perm(ghi[q], __builtin_amdgcn_perm(glo[q], gc[q], s1), s2);
+                const uint32_t wr = __builtin_amdgcn_perm(rhi[q], __builtin_amdgcn_perm(rlo[q], rc[q], s1), s2);
+                if (xq + i < W) o[i] = make_uint2(wg, wr);
+            }
         } else {
             // mirrored in x: pixels xq .. xq+3 land on bytes W-1-xq down to W-4-xq
             uint8_t *o = rrev + (size_t)b * 6 * plane + (size_t)y * W + (W - 1 - xq);
+            const uint32_t *qs[6] = {gc, glo, ghi, rc, rlo, rhi};
             if (xq + 4 <= W) {
-                const uint32_t q[6] = {
-                    (uint32_t)(rec[3].gc | (rec[2].gc << 8) | (rec[1].gc << 16) | (rec[0].gc << 24)),
-                    (uint32_t)(rec[3].glo | (rec[2].glo << 8) | (rec[1].glo << 16) | (rec[0].glo << 24)),
-                    (uint32_t)(rec[3].ghi | (rec[2].ghi << 8) | (rec[1].ghi << 16) | (rec[0].ghi << 24)),
-                    (uint32_t)(rec[3].rc | (rec[2].rc << 8) | (rec[1].rc << 16) | (rec[0].rc << 24)),
-                    (uint32_t)(rec[3].rlo | (rec[2].rlo << 8) | (rec[1].rlo << 16) | (rec[0].rlo << 24)),
-                    (uint32_t)(rec[3].rhi | (rec[2].rhi << 8) | (rec[1].rhi << 16) | (rec[0].rhi << 24))};
 #pragma unroll
-                for (int j = 0; j < 6; j++) __builtin_memcpy(o - 3 + j * plane, &q[j], 4);
+                for (int jj = 0; jj < 6; jj++) {
+                    const uint32_t qw = __builtin_amdgcn_perm(qs[jj][0], qs[jj][1], 0x04060002u);   // pixels 3, 2, 1, 0
+                    __builtin_memcpy(o - 3 + jj * plane, &qw, 4);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (xq + i < W) {
-                        uint8_t *oi = o - i;
-                        oi[0] = (uint8_t)rec[i].gc; oi[plane] = (uint8_t)rec[i].glo; oi[2 * plane] = (uint8_t)rec[i].ghi;
-                        oi[3 * plane] = (uint8_t)rec[i].rc; oi[4 * plane] = (uint8_t)rec[i].rlo; oi[5 * plane] = (uint8_t)rec[i].rhi;
+#pragma unroll
+                        for (int jj = 0; jj < 6; jj++) (o - i)[jj * plane] = (uint8_t)(qs[jj][i >> 1] >> (16 * (i & 1)));
                     }
             }
         }
