@@ -582,7 +582,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 // image column -> winner of that column).  Every thread therefore owns LR_ILP columns and issues the
 // loads of all of them, to clamped addresses, before it uses any.
 // ---------------------------------------------------------------------------------------------
-constexpr int LR_ILP = 4;
+constexpr int LR_ILP = 5;     // 320 columns a turn of the wave: rows of 640, 1280 and 1920 columns divide evenly (measured at 640: 4 / 5 / 10 -> 0.129 / 0.114 / 0.139 ms per 256 frames)
 constexpr int LR_THREADS = 64; // one wave per row: measured fastest, and the barriers cost nothing
 
 __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__restrict__ wta, const int16_t *__restrict__ dsub,
