@@ -675,6 +675,81 @@ __global__ void __launch_bounds__(256) k_lrcheck(SgbmGeom g, const uint32_t *__r
     }
 }
 
+// The same check for rows of at most TURNS * LR_ILP * LR_THREADS columns, one wave per row: every global value the wave
+// needs (the keys for the second map, and per image column the key and the sub-pixel disparity again) is requested before
+// the first is used, so a row costs one memory round trip and two passes over LDS instead of one round trip per turn and
+// pass.  Same operations on the same values as k_lrcheck.
+template <int TURNS>
+__global__ void __launch_bounds__(LR_THREADS) k_lrcheck_row(SgbmGeom g, const uint32_t *__restrict__ wta, const int16_t *__restrict__ dsub,
+                                                            int16_t *__restrict__ raw)
+{
+    extern __shared__ uint32_t key2[];
+    constexpr int N = TURNS * LR_ILP;      // columns per thread
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int W = g.W, W1 = g.W1;
+    const uint32_t *w = wta + (size_t)row * W1;
+    const int16_t *ds = dsub + (size_t)row * W1;
+    uint32_t k[N], kw[N];
+    int d1[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int xc = i * LR_THREADS + tid;
+        k[i] = w[min(xc, W1 - 1)];
+        if (xc >= W1) k[i] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int x = i * LR_THREADS + tid;
+        const bool in = x >= g.minX1 && x < g.maxX1 && x < W;
+        const int xc = in ? x - g.minX1 : 0;
+        kw[i] = w[xc];
+        d1[i] = ds[xc];
+        if (!in) kw[i] = 0xffffffffu;
+    }
+    for (int x = tid; x < W; x += LR_THREADS) key2[x] = 0xffffffffu;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int xc = i * LR_THREADS + tid;
+        const int best = (int)(k[i] & 0xffffu);
+        const uint32_t cost = k[i] >> 16;
+        const int x2 = xc + g.minX1 - best - g.minD;
+        if (cost != 65535u && x2 >= 0 && x2 < W) atomicMin(&key2[x2], (cost << 16) | (uint32_t)(0xffff - xc));
+    }
+    __syncthreads();
+    int16_t *out = raw + (size_t)row * W;
+    uint32_t ka[N], kb[N];
+    uint32_t ina = 0, inb = 0;             // bit i: the column that disparity i lands on lies inside the row
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int x = i * LR_THREADS + tid;
+        const int _x = x - (d1[i] >> 4), x_ = x - ((d1[i] + 15) >> 4);
+        const bool a_in = _x >= 0 && _x < W, b_in = x_ >= 0 && x_ < W;
+        ina |= (uint32_t)a_in << i;
+        inb |= (uint32_t)b_in << i;
+        ka[i] = key2[a_in ? _x : 0];
+        kb[i] = key2[b_in ? x_ : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int x = i * LR_THREADS + tid;
+        if (x >= W) continue;
+        int val = g.invalid16;
+        if (kw[i] != 0xffffffffu) {
+            val = d1[i];
+            if (val != g.invalid16) {
+                const int _d = val >> 4, d_ = (val + 15) >> 4;
+                const int va = ka[i] == 0xffffffffu ? g.invalid16 : (0xffff - (int)(ka[i] & 0xffffu)) + g.minX1 - (x - _d);
+                const int vb = kb[i] == 0xffffffffu ? g.invalid16 : (0xffff - (int)(kb[i] & 0xffffu)) + g.minX1 - (x - d_);
+                const bool c1 = ((ina >> i) & 1u) && va >= g.minD && abs(va - _d) > g.disp12MaxDiff;
+                const bool c2 = ((inb >> i) & 1u) && vb >= g.minD && abs(vb - d_) > g.disp12MaxDiff;
+                if (c1 && c2) val = g.invalid16;
+            }
+        }
+        out[x] = (int16_t)val;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K5: 3x3 median of int16 with replicated border
 // ---------------------------------------------------------------------------------------------
@@ -1413,7 +1488,17 @@ static int sgbm_run_part(l3d_sgbm *h, const uint8_t *d_left, const uint8_t *d_ri
         return L3D_ERR_UNSUPPORTED;
     }
     stamp();
-    hipLaunchKernelGGL(k_lrcheck, dim3(B * g.H), dim3(LR_THREADS), (size_t)g.W * 4, s, g, h->wta, h->dsub, h->raw);
+    {
+        // rows that fit into a few turns of one wave take the variant with all loads in flight (640 columns: 2 turns)
+        const int turns = cdiv(std::max(g.W, g.W1), LR_ILP * LR_THREADS);
+        const bool checks = g.disp12MaxDiff <= g.D + 1;   // otherwise k_lrcheck only copies
+        const dim3 grid(B * g.H), block(LR_THREADS);
+        const size_t lds = (size_t)g.W * 4;
+        if (checks && turns <= 2) hipLaunchKernelGGL(k_lrcheck_row<2>, grid, block, lds, s, g, h->wta, h->dsub, h->raw);
+        else if (checks && turns <= 4) hipLaunchKernelGGL(k_lrcheck_row<4>, grid, block, lds, s, g, h->wta, h->dsub, h->raw);
+        else if (checks && turns <= 6) hipLaunchKernelGGL(k_lrcheck_row<6>, grid, block, lds, s, g, h->wta, h->dsub, h->raw);
+        else hipLaunchKernelGGL(k_lrcheck, grid, block, lds, s, g, h->wta, h->dsub, h->raw);
+    }
     stamp();
     {
         const int rc = sgbm_post(h, B, d_disp, s, stamp);

@@ -93,6 +93,10 @@ def test_gray_bit_exact(gpu, O):
     (300, 48, 144, 5, 0, dict(uniquenessRatio=130)),                   # ... with padding disparities in the record
     (260, 60, 96, 9, 0, dict(uniquenessRatio=40)),                     # two and four lanes to a column in the uniqueness scan
     (300, 40, 256, 5, 0, dict(uniquenessRatio=25)),
+    # wide rows: the left-right check's variants for up to 1280 and 1920 columns, and its general form beyond that
+    (1000, 24, 64, 5, 0, {}),
+    (1700, 24, 64, 5, 7, {}),
+    (2100, 22, 64, 5, -5, {}),
 ])
 def test_sgbm_every_stage_bit_exact(gpu, O, W, H, D, b, mind, extra):
     kw = _ref_ctor(D, b)
