@@ -755,8 +755,11 @@ __global__ void __launch_bounds__(LR_THREADS) k_lrcheck_row(SgbmGeom g, const ui
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void srt(int &a, int &b) { const int t = min(a, b); b = max(a, b); a = t; }
 
-__global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst)
+// (Both median kernels also put the word at `zero`, if given, to zero: the counter of the speckle filter's kernels, which
+// run next on the stream -- a separate clear would be one more dependent launch in the chain.)
+__global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst, int *__restrict__ zero)
 {
+    if (zero && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *zero = 0;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
@@ -783,8 +786,9 @@ __device__ __forceinline__ uint32_t pk_med3(uint32_t a, uint32_t b, uint32_t c)
     return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
 }
 
-__global__ void __launch_bounds__(256) k_median3_pairs(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_median3_pairs(const int16_t *__restrict__ src, int W, int H, int16_t *__restrict__ dst, int *__restrict__ zero)
 {
+    if (zero && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0) *zero = 0;
     const int WP = W >> 1;
     const int xp = blockIdx.x * blockDim.x + threadIdx.x;
     if (xp >= WP) return;
@@ -819,12 +823,12 @@ __global__ void __launch_bounds__(256) k_median3_pairs(const int16_t *__restrict
     }
 }
 
-static void launch_median3(const int16_t *src, int W, int H, int B, int16_t *dst, hipStream_t s)
+static void launch_median3(const int16_t *src, int W, int H, int B, int16_t *dst, hipStream_t s, int *zero = nullptr)
 {
     if ((W & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0)
-        hipLaunchKernelGGL(k_median3_pairs, dim3(cdiv(W >> 1, 64), cdiv(H, 4 * MEDIAN_ROWS), B), dim3(64, 4), 0, s, src, W, H, dst);
+        hipLaunchKernelGGL(k_median3_pairs, dim3(cdiv(W >> 1, 64), cdiv(H, 4 * MEDIAN_ROWS), B), dim3(64, 4), 0, s, src, W, H, dst, zero);
     else
-        hipLaunchKernelGGL(k_median3, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, src, W, H, dst);
+        hipLaunchKernelGGL(k_median3, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, src, W, H, dst, zero);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1413,12 +1417,11 @@ static int sgbm_post(l3d_sgbm *h, int B, int16_t *d_disp, hipStream_t s, Stamp &
 {
     const SgbmGeom &g = h->g;
     const bool speckle = g.speckleWindowSize > 0;
-    launch_median3(h->raw, g.W, g.H, B, d_disp, s);
+    launch_median3(h->raw, g.W, g.H, B, d_disp, s, speckle ? h->pend : nullptr);   // (and the counter of pending components to zero)
     stamp();
     if (speckle) {
         const int newVal = g.invalid16, maxDiff = 16 * g.speckleRange, maxSize = g.speckleWindowSize;
         const size_t pairs = (size_t)B * ((size_t)((g.W - 1) / ST) * g.H + (size_t)((g.H - 1) / STH) * g.W);
-        L3D_HIP_CHECK(hipMemsetAsync(h->pend, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_speckle_tile, dim3(cdiv(g.W, ST), cdiv(g.H, STH), B), dim3(256), 0, s, d_disp, g.W, g.H, newVal, maxDiff, maxSize,
                            h->labels, h->tsizes, h->sizes, h->pend + 1, h->pend, h->tflags);
         if (pairs)
