@@ -39,16 +39,19 @@ CONFIGS = {
     # what the reference's own constructor picks for a 640-px-wide eye (camera/single_usb_stereo_camera.py:239-282)
     "REFDEFAULT": (640, 360, 96, 7, True, 8000.0, 1.5),
 }
-DEFAULT_BATCH = {"C2": 256, "C3": 128, "C4": 32, "C5": 32, "REFDEFAULT": 128}
+DEFAULT_BATCH = {"C2": 256, "C3": 128, "C5": 32, "REFDEFAULT": 128}
 C4_STREAMS = 8
+C4_FRAMES_PER_RANK = 256     # a rank batches ceil(256 / streams it owns) consecutive frames of each of its streams per step
+ALSO_CONFIGS = ("C3", "C5", "REFDEFAULT")
 LASER_PLANE = np.array([0.0, 0.0, 1.0, -0.5])   # z = 0.5 m, the plane of the reference-generated golden vectors
 
 
 def alg_bytes(W, H, D, use_wls, n_pts, xyz=False):
     """Algorithmic HBM bytes per frame pair: one SGBM pass = two u8 inputs + s16 output + one write and one read of
-    the s16 cost volume = 4*W*H*(1+D); WLS adds a second pass + 103*W*H; reprojection 16*W*H; Steger 3*W*H + 8*n_pts."""
+    the s16 cost volume = 4*W*H*(1+D); WLS adds a second pass + 103*W*H; depth: 16*W*H when the XYZ image is written
+    (f32 disparity in, XYZ out), 6*W*H when only Z is (s16 disparity in, f32 Z out); Steger 3*W*H + 8*n_pts."""
     sgbm = 4 * W * H * (1 + D)
-    total = sgbm + 16 * W * H + 3 * W * H + 8 * n_pts
+    total = sgbm + (16 if xyz else 6) * W * H + 3 * W * H + 8 * n_pts
     if use_wls:
         total += sgbm + 103 * W * H
     return sgbm, total
@@ -96,6 +99,79 @@ def spawn_ranks_if_needed(args, argv, environ=os.environ, run=subprocess.call):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return run(launcher_command(args.gpus, argv), env=env)
+
+
+def plan_frames(config, batch, rank, world):
+    """(frames per step of this rank, their ids, scaling, sharding).  C4 = whole streams (stream s on rank s % world): the
+    frames of a stream are independent of each other, so a rank takes ceil(256 / streams it owns) consecutive frames of
+    each of its streams into one launch -- every rank launches about 256 frames whatever N is, and the frames per step of
+    the whole job grow with N (weak scaling over a fixed set of 8 streams).  Otherwise frames round-robin."""
+    from laser_3d_reconstruction_amd import parallel
+
+    if config == "C4":
+        my_streams = parallel.shard_indices(C4_STREAMS, rank, world)
+        if not my_streams:
+            raise SystemExit(f"rank {rank} owns no stream: C4 needs --gpus <= {C4_STREAMS}")
+        per_stream = batch if batch else -(-C4_FRAMES_PER_RANK // len(my_streams))
+        ids = [10_000 * (s + 1) + i for s in my_streams for i in range(per_stream)]
+        return per_stream * len(my_streams), ids, "weak", (f"{C4_STREAMS} streams over {world} rank(s), stream s on rank s % {world}, "
+                                                           f"{per_stream} frames per stream per step")
+    B = batch if batch else DEFAULT_BATCH.get(config, 64)
+    return B, parallel.shard_indices(B * world, rank, world), "weak", f"frames x{world}"
+
+
+def _pair_job(job):
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+
+    W, H, D, k = job
+    return S.stereo_pair(W, H, D, k)[:2]
+
+
+def host_frames(W, H, D, frame_ids):
+    """The synthetic pairs of this rank, every frame distinct, generated by worker processes (forked: call before this
+    process touches the GPU).  Returns two uint8 arrays (B, H, W, 3)."""
+    import multiprocessing as mp
+
+    workers = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16") or 16), os.cpu_count() or 1, len(frame_ids)))
+    jobs = [(W, H, D, k) for k in frame_ids]
+    if workers > 1:
+        try:
+            with mp.get_context("fork").Pool(workers) as pool:
+                pairs = pool.map(_pair_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+        except Exception:
+            pairs = [_pair_job(j) for j in jobs]
+    else:
+        pairs = [_pair_job(j) for j in jobs]
+    return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+
+def also_configs(steps=5, warmup=2, repeats=3, run=subprocess.run):
+    """The other single-GPU workloads as short runs of this script, one child process each, before this process
+    touches the GPU.  Returns {config: summary of the child's JSON line}."""
+    out = {}
+    for cfg in ALSO_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup),
+               "--repeats", str(repeats), "--no-cpu-baseline", "--no-also"]
+        t0 = time.perf_counter()
+        try:
+            r = run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[cfg] = {"error": f"exit {r.returncode}: " + (r.stderr or "")[-300:]}
+                continue
+            d = json.loads(line[-1])
+            out[cfg] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "repeats": d["timing"]["repeats"], "batch_per_gpu": d["config"]["batch_per_gpu"],
+                        "workload": d["config"]["workload"], "verified": d["verified"],
+                        "roofline": {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic")},
+                        "pipeline_roofline_frac": d["pipeline_roofline"]["frac"],
+                        "kernel_ms_per_launch": {k: v for k, v in d["kernel_ms_per_launch"].items()
+                                                 if "vertical" in k or "horizontal" in k},
+                        "stage_ms_per_step_serialised": d["stage_ms_per_step_serialised"],
+                        "wall_s": time.perf_counter() - t0}
+        except Exception as e:      # a failed side run must not lose the headline measurement
+            out[cfg] = {"error": repr(e)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -191,6 +267,8 @@ def main(argv=None):
     ap.add_argument("--sgbm-mode", type=int, default=2, choices=[0, 1, 2],
                     help="2: MODE_SGBM_3WAY, the reference's mode and the benchmark; 0 / 1: MODE_SGBM / MODE_HH (5 / 8 paths), GPU leg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short runs of C3 / C5 / REFDEFAULT that the default C2 run on one GPU adds as \"also\"")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args(argv)
 
@@ -210,13 +288,20 @@ def main(argv=None):
     W, H, D, block, use_wls, lam, sigma = CONFIGS[args.config]
     want_xyz = args.config == "C5"
 
-    # the CPU leg first: its worker processes are forked, which must happen before this process holds a GPU
+    # The other workloads first, as child processes of their own (this process has not touched the GPU yet), then the
+    # CPU leg and the synthetic frames, whose worker processes are forked: all before this process holds a GPU.
+    also = None
+    if rank == 0 and world == 1 and "WORLD_SIZE" not in os.environ and args.config == "C2" and args.sgbm_mode == 2 and not args.no_also:
+        also = also_configs()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sgbm_mode == 2:
         try:
             cpu = cpu_baseline(W, H, D, block, use_wls, lam, sigma, want_xyz)
         except Exception as e:
             cpu = {"error": repr(e)}
+
+    B, frame_ids, scaling, sharding = plan_frames(args.config, args.batch, rank, world)
+    np_l, np_r = host_frames(W, H, D, frame_ids)
 
     import torch
     import torch.distributed as dist
@@ -244,19 +329,6 @@ def main(argv=None):
     from laser_3d_reconstruction_amd.core.reconstruction import Reconstructor
     from laser_3d_reconstruction_amd.utils import synthetic as S
 
-    # frames of this rank: C4 = whole streams (stream s on rank s % world), otherwise frames round-robin
-    if args.config == "C4":
-        per_stream = args.batch if args.batch else DEFAULT_BATCH["C4"]
-        my_streams = parallel.shard_indices(C4_STREAMS, rank, world)
-        B = per_stream * len(my_streams)
-        frame_ids = [10_000 * (s + 1) + i for s in my_streams for i in range(per_stream)]
-        scaling, sharding = "strong", f"{C4_STREAMS} streams over {world} rank(s), stream s on rank s % {world}"
-    else:
-        B = args.batch if args.batch else DEFAULT_BATCH.get(args.config, 64)
-        frame_ids = parallel.shard_indices(B * world, rank, world)
-        scaling, sharding = "weak", f"frames x{world}"
-    if B == 0:
-        raise SystemExit(f"rank {rank} owns no stream: C4 needs --gpus <= {C4_STREAMS}")
 
     # start-up: rank 0 owns the calibration -- K/D/R/T, Q and the four rectification maps -- and broadcasts it (the
     # only collective of the job).  Timed twice, with and without the maps in the payload.
@@ -283,10 +355,9 @@ def main(argv=None):
     rect = rectify.Rectifier.from_maps(calib["map_left_x"], calib["map_left_y"], device=local_rank)
 
     # synthetic frames of this rank's shard, every frame of the batch distinct, uploaded once
-    pairs = [S.stereo_pair(W, H, D, k) for k in frame_ids]
-    h_l = torch.from_numpy(np.stack([p[0] for p in pairs])).pin_memory()
-    h_r = torch.from_numpy(np.stack([p[1] for p in pairs])).pin_memory()
-    del pairs
+    h_l = torch.from_numpy(np_l).pin_memory()
+    h_r = torch.from_numpy(np_r).pin_memory()
+    del np_l, np_r
     d_l, d_r = h_l.to(dev), h_r.to(dev)
 
     recon = Reconstructor(K, LASER_PLANE, use_refraction_correction=True, device=local_rank)
@@ -553,6 +624,10 @@ def main(argv=None):
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        elif world > 1:
+            out["cpu_baseline_note"] = "reported by the N = 1 run only (rank 0, before the GPU is touched)"
+        if also is not None:
+            out["also"] = also
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:

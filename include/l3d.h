@@ -64,7 +64,13 @@ typedef struct {
     int speckleWindowSize;
     int speckleRange;
     int mode;              /* 2 = cv2.STEREO_SGBM_MODE_SGBM_3WAY (what the reference passes, :273); 0 = MODE_SGBM (5 paths),
-                              1 = MODE_HH (8 paths); 3 = MODE_HH4 is not built */
+                              1 = MODE_HH (8 paths); 3 = MODE_HH4 is not built.
+                              Modes 0 and 1 are not on the reference's path; their parity with OpenCV is unpinned (checked
+                              against the CPU restatement of computeDisparitySGBM only).  They keep the aggregated-cost and
+                              the summed-cost volume of whole images in device memory:
+                              2 * max_batch * H * (W - numDisparities) * Dp * 2 bytes (Dp = numDisparities rounded up to what
+                              the lane layout holds, at most + 16), against one volume of H + 4 rows for mode 2, and their
+                              row passes read the volume with a stride (about 4-5 x slower than mode 2). */
 } l3d_sgbm_params;
 
 typedef struct l3d_sgbm l3d_sgbm;
@@ -193,7 +199,11 @@ void l3d_steger_destroy(l3d_steger *h);
  * stored and L3D_ERR_CAPACITY is returned). */
 int l3d_steger_extract(l3d_steger *h, const uint8_t *img, int channels, int width, int height, int batch,
                        const int *roi, float *xy, int capacity, int *counts);
-/* device operands; d_xy [batch][capacity][2] float, d_counts [batch] int */
+/* device operands; d_xy [batch][capacity][2] float, d_counts [batch] int.
+ * All calls on one handle share its work buffers and must be ordered on the device: use one stream, or order the
+ * streams with events.  (A call leaves the buffers in the state the next call expects; a call on another stream than
+ * the previous one, and a call after one that failed, clear them first -- which is only safe once the previous call's
+ * kernels have run.) */
 int l3d_steger_extract_device(l3d_steger *h, const uint8_t *d_img, int channels, int width, int height,
                               int batch, const int *roi, float *d_xy, int capacity, int *d_counts,
                               void *stream);

@@ -428,7 +428,13 @@ int depth_from_disp16_lut(const int16_t *d_disp16, const double *Q16_host, size_
     if (!same) {
         QMat Q;
         for (int i = 0; i < 16; i++) Q.q[i] = Q16_host ? Q16_host[i] : 0.0;
+        // The table is rebuilt only when Q changes (once per calibration).  Later calls may come on other streams and
+        // skip the build, so the build is waited for here: whichever stream applies the table next reads a complete
+        // one.  The record of what the table holds is updated only once the build has succeeded.
+        lut_Q[16] = -1.0;
         hipLaunchKernelGGL(k_depth_lut_build, dim3(256), dim3(256), 0, stream, Q, Q16_host ? 1 : 0, d_lut);
+        L3D_HIP_CHECK(hipGetLastError());
+        L3D_HIP_CHECK(hipStreamSynchronize(stream));
         for (int i = 0; i < 16; i++) lut_Q[i] = Q.q[i];
         lut_Q[16] = Q16_host ? 1.0 : 0.0;
     }

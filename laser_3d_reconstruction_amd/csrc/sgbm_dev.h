@@ -140,6 +140,12 @@ struct alignas(NP == 1 ? 4 : (NP == 2 ? 8 : (NP % 4 == 0 ? 16 : (NP % 2 == 0 ? 8
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Views for memory that is also accessed through another type (the LDS records of summed costs are written as packed
+// words and read as single 16-bit entries, and the other way round): may_alias makes those accesses well defined, so
+// their order does not hang on a compiler barrier between them.
+typedef u32x4 __attribute__((may_alias)) u32x4_any;
+template <int NP>
+using PackAny __attribute__((may_alias)) = Pack<NP>;
 template <int NP>
 __device__ __forceinline__ Pack<NP> buf_load(BufRsrc r, uint32_t voff, uint32_t soff)
 {

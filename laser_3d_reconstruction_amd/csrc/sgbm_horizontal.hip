@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
                 const bool lo = uniq_f > 0;
                 const int16_t never = lo ? (int16_t)32767 : (int16_t)-32768;
                 if (e_h == 0) { rec[best - 1] = never; rec[best] = never; rec[best + 1] = never; }
-                asm volatile("" ::: "memory");   // the scan below reads the record through another type: keep it behind the three stores
-                const u32x4 *q = reinterpret_cast<const u32x4 *>(rec + e_h * 2 * WPL);
+                // (the scan below reads the record through a may_alias vector type, so it stays behind the three stores)
+                const u32x4_any *q = reinterpret_cast<const u32x4_any *>(rec + e_h * 2 * WPL);
                 int m;
                 if (lo) {
                     uint32_t acc = 0x7fff7fffu;
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(64) k_horizontal(SgbmGeom g, int nrows_total, 
 #pragma unroll
                 for (int p = 0; p < NP; p++) S.v[p] = pk_adds(UF ? pk_add(rst[p], Lseg[u][p]) : pk_adds(rst[p], Lseg[u][p]), tu[p]);
                 const uint32_t key = wta_min_key<NP, LPP>(S.v, d0);
-                *reinterpret_cast<Pack<NP> *>(sS + 8 + (grp * SSEG + u % SSEG) * REC + d0) = S;
+                *reinterpret_cast<PackAny<NP> *>(sS + 8 + (grp * SSEG + u % SSEG) * REC + d0) = S;
                 if (first) sK[grp * SSEG + u % SSEG] = key;
             }
             if (u % SSEG == 0) seg_step(j, u / SSEG);

@@ -78,6 +78,10 @@ __global__ void __launch_bounds__(64) k_path(SgbmGeom g, int B, int dx, int dy, 
         if (act) {
             Pack<NP> o;
 #pragma unroll
+            // One saturating addition per path, in the order the paths run, equals the definition's single saturation
+            // of the whole sum: the cost is carried with P2 added, so every path cost st is >= 0 (it is at least
+            // c + P2 - (previous minimum + P2) + previous minimum >= 0 from costs c >= 0) and the partial sums only
+            // grow -- once one of them reaches 32767 it stays there, exactly where the full sum would be clamped.
             for (int p = 0; p < NP; p++) o.v[p] = overwrite ? st[p] : pk_adds(s.v[p], st[p]);
             *reinterpret_cast<Pack<NP> *>(Svol + idx) = o;
         }
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(64) k_wta_s(SgbmGeom g, long long ncols, const
         const long long col = min(base + grp, ncols - 1);
         const Pack<NP> S = *reinterpret_cast<const Pack<NP> *>(Svol + col * CW + l * NP);
         const uint32_t key = wta_key<NP, LPP>(g, S.v, d0, sWin);
-        *reinterpret_cast<Pack<NP> *>(sS + 8 + grp * REC + d0) = S;
+        *reinterpret_cast<PackAny<NP> *>(sS + 8 + grp * REC + d0) = S;
         if (l == 0) sK[grp] = key;
         __syncthreads();
         if (tid < PPW && base + tid < ncols) {

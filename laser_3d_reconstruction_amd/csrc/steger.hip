@@ -559,8 +559,14 @@ struct l3d_steger {
     // which is what the next call expects.
     // `dirty` says that this may not hold (before the first call, and after a call that failed half way): the next
     // call then clears both arrays first.  The static work array has one such flag per device instead.
+    // All calls on one handle must be ordered on the device (one stream, or streams the caller orders with events): the
+    // arrays are shared.  A call on another stream than the previous one cannot know that the previous call has run,
+    // so it clears first as well (`last`: the previous call's stream; the static array keeps one per device).
+    struct StreamNote { hipStream_t stream = nullptr; bool any = false; };
     bool dirty_own = true;
     bool *dirty = nullptr;
+    StreamNote last_own;
+    StreamNote *last = nullptr;
     size_t max_tiles = 0;
     // staging for the host entry point
     uint8_t *in = nullptr;
@@ -695,6 +701,9 @@ static int steger_run(l3d_steger *h, const uint8_t *d_img, int channels, int W, 
     L3D_REQUIRE((size_t)B * a.rh * a.ntx <= h->cells_capacity, "steger: %zu cells exceed the %zu the work buffers hold", (size_t)B * a.rh * a.ntx,
                 h->cells_capacity);
     bool &dirty = h->dirty ? *h->dirty : h->dirty_own;
+    l3d_steger::StreamNote &last = h->last ? *h->last : h->last_own;
+    if (last.any && last.stream != s) dirty = true;
+    last.stream = s; last.any = true;
     if (dirty) {
         const size_t n_tiles = 1 + h->max_tiles, n_cells = h->cells_capacity;
         hipLaunchKernelGGL(k_steger_clear, dim3((unsigned)std::min<size_t>((std::max(n_tiles, n_cells) + 1023) / 1024, 2048)), dim3(256), 0, s,
@@ -836,13 +845,14 @@ extern "C" int l3d_steger_extract_device_static(double sigma, int brightness_thr
     v.cell_counts = reinterpret_cast<int *>(base + kStaticTapsBytes + kStaticListBytes);
     v.cells = reinterpret_cast<float2 *>(base + kStaticTapsBytes + kStaticListBytes + kStaticCountBytes);
     v.max_tiles = kStaticCells;
-    static bool static_dirty[kMaxDevices];
-    static bool static_dirty_init = false;
-    if (!static_dirty_init) {
-        for (bool &d : static_dirty) d = true;
-        static_dirty_init = true;
-    }
-    v.dirty = &static_dirty[device < kMaxDevices ? device : 0];
+    // One flag and one stream note per device, constant-initialised (no set-up step that first calls on different
+    // GPUs could race on): the device array is zero when the library is loaded, which is the state a call expects, so
+    // a device starts clean; it is marked again by a call that fails half way (steger_run).  Threads that call for
+    // different GPUs touch different elements; calls for one GPU must not overlap anyway.
+    static bool static_dirty[kMaxDevices] = {};
+    static l3d_steger::StreamNote static_last[kMaxDevices] = {};
+    v.dirty = &static_dirty[device];
+    v.last = &static_last[device];
     v.max_cells = (size_t)height * cdiv(width, TW);
     v.cells_capacity = kStaticCells;
     hipStream_t s = (hipStream_t)stream;

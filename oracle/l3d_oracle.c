@@ -949,6 +949,17 @@ static void gauss_blur_f32(const float *src, int w, int h, const float *taps, in
     free(tmp);
 }
 
+/* cv2.GaussianBlur(src_f32, (0, 0), sigma, sigma) as restated above, exported for the golden-vector generator
+ * (tests/golden/make_laser_golden.py), which runs the reference's own per-pixel code on these images. */
+ORC_API int orc_gauss_blur_f32(const float *src, int w, int h, double sigma, float *dst)
+{
+    float taps[512];
+    int ks = orc_gauss_kernel(sigma, taps, 512);
+    if (ks < 0) return -1;
+    gauss_blur_f32(src, w, h, taps, ks, dst);
+    return 0;
+}
+
 /* Steger decision for one pixel from the five derivative images.
  * returns 1 and writes (ox, oy) offsets if accepted. */
 static int steger_point(float dx, float dy, float dxx, float dyy, float dxy, double *ox, double *oy)
@@ -1153,29 +1164,14 @@ static void morph3x3(const uint8_t *src, int W, int H, int dilate, uint8_t *dst)
         }
 }
 
-/* dbg (optional): 3 planes W*H: combined mask, mask after morphology, final filled mask */
-ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_stride, const int *lower, const int *upper,
-                               int brightness_threshold, double min_area, double *xy, int *count, uint8_t *dbg)
-{
-    hsv_tables();
-    const size_t n = (size_t)W * H;
-    uint8_t *gray = (uint8_t *)malloc(n), *m0 = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n), *fin = (uint8_t *)calloc(n, 1);
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const uint8_t *px = bgr + (ptrdiff_t)y * row_stride + 3 * x;
-            int hh, ss, vv;
-            bgr2hsv_px(px[0], px[1], px[2], &hh, &ss, &vv);
-            int g = (px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15;
-            gray[(size_t)y * W + x] = (uint8_t)g;
-            int in = hh >= lower[0] && hh <= upper[0] && ss >= lower[1] && ss <= upper[1] && vv >= lower[2] && vv <= upper[2];
-            m0[(size_t)y * W + x] = (in && g > brightness_threshold) ? 255 : 0;
-        }
-    if (dbg) memcpy(dbg, m0, n);
-    morph3x3(m0, W, H, 1, m1); morph3x3(m1, W, H, 0, m0);   /* close = erode(dilate) */
-    morph3x3(m0, W, H, 0, m1); morph3x3(m1, W, H, 1, m0);   /* open  = dilate(erode) */
-    if (dbg) memcpy(dbg + n, m0, n);
 
-    /* padded binary image, 1-pixel zero frame */
+/* External contours of a binary mask the way cv2.findContours(RETR_EXTERNAL) orders and traces them: every top-level
+ * 8-connected component (one that touches background 4-connected to the image frame), in raster order of its first
+ * pixel, Suzuki-Abe border following from that pixel.  visit(chain, nchain, PW, ctx) gets the traced chain as indices
+ * into the image padded by a 1-pixel zero frame (row = idx / PW - 1, column = idx % PW - 1). */
+typedef void (*orc_chain_fn)(const int *chain, int nchain, int PW, void *ctx);
+static void trace_external_contours(const uint8_t *m0, int W, int H, orc_chain_fn visit, void *ctx)
+{
     const int PW = W + 2, PH = H + 2;
     uint8_t *f = (uint8_t *)calloc((size_t)PW * PH, 1);
     for (int y = 0; y < H; y++)
@@ -1202,7 +1198,6 @@ ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_s
     static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1}, DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     int ncomp = 0;
     int *chain = (int *)malloc((size_t)PW * PH * 4 * sizeof(int)); /* a border pixel is visited at most 4 times */
-    double *cross_x = (double *)malloc(((size_t)PW + 4) * sizeof(double));
     for (int i = 1; i <= H; i++)
         for (int j = 1; j <= W; j++) {
             int s = i * PW + j;
@@ -1245,43 +1240,124 @@ ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_s
                     chain[nchain++] = i3 * PW + j3;
                 }
             }
-            /* cv2.contourArea: |sum(prev.x * p.y - prev.y * p.x)| / 2 */
-            double a00 = 0;
-            {
-                int prev = chain[nchain - 1];
-                for (int k = 0; k < nchain; k++) {
-                    int p = chain[k];
-                    double px_ = prev % PW, py_ = prev / PW, qx = p % PW, qy = p / PW;
-                    a00 += px_ * qy - py_ * qx;
-                    prev = p;
-                }
-            }
-            if (!(fabs(a00 * 0.5) > min_area)) continue;
-            /* cv2.drawContours(..., thickness=-1): chain pixels + even-odd interior */
-            int ymin = PH, ymax = -1;
-            for (int k = 0; k < nchain; k++) {
-                int p = chain[k];
-                fin[(size_t)(p / PW - 1) * W + (p % PW - 1)] = 255;
-                ymin = imin(ymin, p / PW); ymax = imax(ymax, p / PW);
-            }
-            for (int y = ymin; y <= ymax; y++) {
-                int nc = 0;
-                for (int k = 0; k < nchain; k++) {
-                    int a = chain[k], b = chain[(k + 1) % nchain];
-                    int y1 = a / PW, y2 = b / PW;
-                    if ((y1 <= y) == (y2 <= y)) continue;
-                    cross_x[nc++] = (y1 < y2) ? (double)(a % PW) : (double)(b % PW); /* x at the endpoint on row y */
-                    if (nc >= PW + 4) { /* grow */
-                        cross_x = (double *)realloc(cross_x, (size_t)(nc + PW + 4) * 2 * sizeof(double));
-                    }
-                }
-                for (int x = 1; x <= W; x++) {
-                    int c = 0;
-                    for (int k = 0; k < nc; k++) c += cross_x[k] > x;
-                    if (c & 1) fin[(size_t)(y - 1) * W + (x - 1)] = 255;
-                }
-            }
+            visit(chain, nchain, PW, ctx);
         }
+    free(f); free(comp); free(outer); free(stack); free(chain);
+}
+
+/* cv2.contourArea: |sum(prev.x * p.y - prev.y * p.x)| / 2 */
+static double chain_area(const int *chain, int nchain, int PW)
+{
+    double a00 = 0;
+    int prev = chain[nchain - 1];
+    for (int k = 0; k < nchain; k++) {
+        int p = chain[k];
+        double px_ = prev % PW, py_ = prev / PW, qx = p % PW, qy = p / PW;
+        a00 += px_ * qy - py_ * qx;
+        prev = p;
+    }
+    return fabs(a00 * 0.5);
+}
+
+/* cv2.drawContours(..., thickness=-1) of one contour: chain pixels + even-odd interior */
+static void fill_chain(const int *chain, int nchain, int PW, int W, int H, uint8_t *fin, uint8_t value)
+{
+    (void)H;
+    const int PH = H + 2;
+    double *cross_x = (double *)malloc(((size_t)nchain + 4) * sizeof(double));
+    int ymin = PH, ymax = -1;
+    for (int k = 0; k < nchain; k++) {
+        int p = chain[k];
+        fin[(size_t)(p / PW - 1) * W + (p % PW - 1)] = value;
+        ymin = imin(ymin, p / PW); ymax = imax(ymax, p / PW);
+    }
+    for (int y = ymin; y <= ymax; y++) {
+        int nc = 0;
+        for (int k = 0; k < nchain; k++) {
+            int a = chain[k], b = chain[(k + 1) % nchain];
+            int y1 = a / PW, y2 = b / PW;
+            if ((y1 <= y) == (y2 <= y)) continue;
+            cross_x[nc++] = (y1 < y2) ? (double)(a % PW) : (double)(b % PW); /* x at the endpoint on row y */
+        }
+        for (int x = 1; x <= W; x++) {
+            int c = 0;
+            for (int k = 0; k < nc; k++) c += cross_x[k] > x;
+            if (c & 1) fin[(size_t)(y - 1) * W + (x - 1)] = value;
+        }
+    }
+    free(cross_x);
+}
+
+struct simple_fill_ctx { int W, H; double min_area; uint8_t *fin; };
+static void simple_fill_visit(const int *chain, int nchain, int PW, void *vctx)
+{
+    struct simple_fill_ctx *c = (struct simple_fill_ctx *)vctx;
+    if (!(chain_area(chain, nchain, PW) > c->min_area)) return;
+    fill_chain(chain, nchain, PW, c->W, c->H, c->fin, 255);
+}
+
+
+/* The pieces of the mask pipeline on their own, for the golden-vector generator (tests/golden/make_laser_golden.py). */
+ORC_API void orc_morph3x3(const uint8_t *src, int W, int H, int dilate, uint8_t *dst) { morph3x3(src, W, H, dilate, dst); }
+
+struct collect_ctx { int *xy; int cap_pts; int *lens; int max_contours; int n, used; };
+static void collect_visit(const int *chain, int nchain, int PW, void *vctx)
+{
+    struct collect_ctx *c = (struct collect_ctx *)vctx;
+    if (c->n < c->max_contours && c->used + nchain <= c->cap_pts) {
+        for (int k = 0; k < nchain; k++) {
+            c->xy[2 * (c->used + k)] = chain[k] % PW - 1;
+            c->xy[2 * (c->used + k) + 1] = chain[k] / PW - 1;
+        }
+        c->lens[c->n] = nchain;
+        c->used += nchain;
+    }
+    c->n++;
+}
+/* Traced external contours as (x, y) points, contour after contour; lens[i] = points of contour i.  Returns the number
+ * of contours found (only those that fit both capacities are stored). */
+ORC_API int orc_find_external_contours(const uint8_t *mask, int W, int H, int *xy, int cap_pts, int *lens, int max_contours)
+{
+    struct collect_ctx c = {xy, cap_pts, lens, max_contours, 0, 0};
+    trace_external_contours(mask, W, H, collect_visit, &c);
+    return c.n;
+}
+/* Fills one traced contour (n points (x, y)) into img. */
+ORC_API void orc_fill_contour(const int *xy, int n, int W, int H, uint8_t *img, int value)
+{
+    const int PW = W + 2;
+    int *chain = (int *)malloc((size_t)n * sizeof(int));
+    for (int k = 0; k < n; k++) chain[k] = (xy[2 * k + 1] + 1) * PW + xy[2 * k] + 1;
+    fill_chain(chain, n, PW, W, H, img, (uint8_t)value);
+    free(chain);
+}
+
+/* dbg (optional): 3 planes W*H: combined mask, mask after morphology, final filled mask */
+ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_stride, const int *lower, const int *upper,
+                               int brightness_threshold, double min_area, double *xy, int *count, uint8_t *dbg)
+{
+    hsv_tables();
+    const size_t n = (size_t)W * H;
+    uint8_t *gray = (uint8_t *)malloc(n), *m0 = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n), *fin = (uint8_t *)calloc(n, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t *px = bgr + (ptrdiff_t)y * row_stride + 3 * x;
+            int hh, ss, vv;
+            bgr2hsv_px(px[0], px[1], px[2], &hh, &ss, &vv);
+            int g = (px[2] * 9798 + px[1] * 19235 + px[0] * 3735 + (1 << 14)) >> 15;
+            gray[(size_t)y * W + x] = (uint8_t)g;
+            int in = hh >= lower[0] && hh <= upper[0] && ss >= lower[1] && ss <= upper[1] && vv >= lower[2] && vv <= upper[2];
+            m0[(size_t)y * W + x] = (in && g > brightness_threshold) ? 255 : 0;
+        }
+    if (dbg) memcpy(dbg, m0, n);
+    morph3x3(m0, W, H, 1, m1); morph3x3(m1, W, H, 0, m0);   /* close = erode(dilate) */
+    morph3x3(m0, W, H, 0, m1); morph3x3(m1, W, H, 1, m0);   /* open  = dilate(erode) */
+    if (dbg) memcpy(dbg + n, m0, n);
+
+    {
+        struct simple_fill_ctx ctx = {W, H, min_area, fin};
+        trace_external_contours(m0, W, H, simple_fill_visit, &ctx);
+    }
     if (dbg) memcpy(dbg + 2 * n, fin, n);
     /* per-row intensity-weighted centroid */
     int m = 0;
@@ -1293,7 +1369,7 @@ ORC_API int orc_simple_extract(const uint8_t *bgr, int W, int H, ptrdiff_t row_s
         if (any && sw > 0) { xy[2 * m] = sxw / sw; xy[2 * m + 1] = (double)y; m++; }
     }
     *count = m;
-    free(gray); free(m0); free(m1); free(fin); free(f); free(comp); free(outer); free(stack); free(chain); free(cross_x);
+    free(gray); free(m0); free(m1); free(fin);
     return 0;
 }
 

@@ -45,6 +45,29 @@ def test_path_modes_every_stage_bit_exact(O, mode, W, H, D, b, over):
     assert (got > (kw["minDisparity"] - 1) * 16).mean() > 0.3
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_path_modes_with_saturating_sums(O, mode):
+    """Uncorrelated low-amplitude noise at block size 11: the path costs are large enough that the sum over 5 / 8 paths
+    passes 32767 at a part of the entries (a sixth to a half), so the saturating additions (one per path, in the
+    definition's order) decide what the stage holds there."""
+    from laser_3d_reconstruction_amd import stereo
+
+    W, H, D, b = 200, 60, 32, 11
+    rng = np.random.default_rng(5 + mode)
+    amp = 12 if mode == 0 else 5
+    gl = (128 + rng.integers(-amp, amp + 1, (H, W))).astype(np.uint8)
+    gr = (128 + rng.integers(-amp, amp + 1, (H, W))).astype(np.uint8)
+    kw = _ctor(D, b)
+    m = stereo.StereoSGBM_create(**kw, mode=mode)
+    got = m.compute(gl, gr)
+    dbg = O.sgbm_compute_debug(O.sgbm_params(**kw, mode=mode), gl, gr)
+    sat = float((dbg.S == 32767).mean())
+    assert int(dbg.S.max()) == 32767 and 0.1 < sat < 0.6, "the case must reach the saturation value at a part of the entries"
+    assert np.array_equal(m.fetch_stage(0, 1, W, H)[0], dbg.C), "aggregated cost volume"
+    assert np.array_equal(m.fetch_stage(1, 1, W, H)[0], dbg.S), "summed path costs"
+    assert np.array_equal(got, dbg.disp), "final disparity"
+
+
 def test_path_modes_differ_and_batches_equal_single_frames(O):
     """The three modes give three different maps on the same pair, and a batch (two half batches on two streams from 8
     frames on) equals its frames run alone."""
