@@ -353,6 +353,19 @@ def test_bench_launcher_plumbing(monkeypatch):
     for world in (1, 2, 4, 8):
         owned = [parallel.shard_indices(bench.C4_STREAMS, r, world) for r in range(world)]
         assert sorted(s for o in owned for s in o) == list(range(8)) and all(len(o) == 8 // world for o in owned)
+        # and a rank's launch holds 256 frames whatever N is: 256 / (streams it owns) consecutive frames of each stream
+        for r in range(world):
+            B, ids, scaling, sharding = bench.plan_frames("C4", None, r, world)
+            assert B == 256 and len(set(ids)) == 256 and scaling == "weak" and f"{256 * world // 8} frames per stream" in sharding
+    assert bench.plan_frames("C4", 2, 1, 2)[0] == 8 and bench.plan_frames("C2", None, 3, 4)[1] == list(range(3, 1024, 4))
+    with pytest.raises(SystemExit):
+        bench.plan_frames("C4", None, 8, 9)
+    # the synthetic frames of a shard come from worker processes and equal the generator's
+    from laser_3d_reconstruction_amd.utils import synthetic as S
+    l, r_ = bench.host_frames(96, 40, 16, [5, 2, 9])
+    assert l.shape == (3, 40, 96, 3) and np.array_equal(l[1], S.stereo_pair(96, 40, 16, 2)[0]) and np.array_equal(r_[2], S.stereo_pair(96, 40, 16, 9)[1])
+    assert bench.alg_bytes(640, 360, 64, False, 0)[1] == 4 * 640 * 360 * 65 + 9 * 640 * 360      # Z-only depth: 6 bytes a pixel
+    assert bench.alg_bytes(640, 360, 64, False, 0, xyz=True)[1] == 4 * 640 * 360 * 65 + 19 * 640 * 360
 
 
 def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
