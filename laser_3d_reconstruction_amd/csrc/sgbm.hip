@@ -223,20 +223,35 @@ __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1
 // One stage = the 6 right-image plane runs widened to 16 bits per value, twice (starting at byte 0 and at byte 1),
 // + 6 words per tile column for the left pixel; `roles` = 8-byte fetches per row
 __host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6 * ((tileC - 1 + D + 3) / 4 + 1) + tileC; }
-// words between the two copies: at least the 6 widened plane runs, and 2 modulo 4.  A lane reads NP consecutive
-// words and its neighbours in the group the next ones, so a group covers every fourth bank (NP = 4); the groups of
-// adjacent columns start one value apart, i.e. in alternating copies and every second time one word lower:
-// with the second copy displaced by 2 banks modulo 4, four adjacent groups start on four different banks modulo 4.
-__host__ __device__ inline int vertical_copy_stride(int tileC, int D)
+// Words between the two copies: at least the 6 widened plane runs, placed so that the reads of a half wave fall on
+// different LDS banks.  A lane reads NP consecutive words, the lanes of its group the next ones (stride NP words), and
+// the groups of adjacent columns start one value apart: in alternating copies, every second time one word lower.  With
+// 8 lanes per pixel a half wave (32 lanes: one ds_read_b32 pass over the 32 banks) holds four groups:
+//   NP = 4: a group covers every fourth bank; a displacement of 2 banks modulo 4 puts four adjacent groups on the four
+//           residues modulo 4;
+//   NP = 2, 6: a group covers eight of the sixteen even (or odd) banks, and the same set moved by 16 is the other eight;
+//           the groups that share a parity sit in different copies, so the displacement is 16 modulo 32.
+// With 16 lanes per pixel (two groups a half wave) an odd NP wants 16 modulo 32 as well and NP = 2, 6 any odd
+// displacement; NP = 4 and 8 cover their banks twice whatever the displacement.  (Found by counting, per bank, the
+// distinct words a half wave requests, for every displacement modulo 32; a stride of 3, 5, 7 words on 8 lanes has no
+// conflict-free displacement.)  With the rule of NP = 4 applied to NP = 6 every read of the staged planes took two
+// LDS cycles: two fifths of the kernel's LDS cycles at 96 disparities were bank conflicts.
+__host__ __device__ inline int vertical_copy_stride(int tileC, int D, int LPP, int NP)
 {
     const int w = 12 * ((tileC - 1 + D + 3) / 4 + 1);
+    const bool want16 = LPP == 8 ? (NP == 2 || NP == 6) : (NP % 2 == 1);
+    const bool want_odd = LPP == 16 && (NP == 2 || NP == 6);
+    if (want16) return (w + 15) / 32 * 32 + 16;
+    if (want_odd) return w | 1;
     return (w + 3) / 4 * 4 + 2;
 }
-__host__ __device__ inline int vertical_stage_words(int tileC, int D) { return 2 * vertical_copy_stride(tileC, D) + 6 * tileC; }
+__host__ __device__ inline int vertical_stage_words(int tileC, int D, int LPP, int NP) { return 2 * vertical_copy_stride(tileC, D, LPP, NP) + 6 * tileC; }
 __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D, bool ring_in_regs = false)
 {
     const int tileC = 256 / LPP + 2 * SW2;
-    return 2 * (size_t)vertical_stage_words(tileC, D) + (size_t)tileC * LPP * NP + (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * 256 * NP);
+    // (the register-ring variants keep two pixel-cost tiles and need one barrier per row)
+    return 2 * (size_t)vertical_stage_words(tileC, D, LPP, NP) + (size_t)tileC * LPP * NP * (ring_in_regs ? 2 : 1) +
+           (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * 256 * NP);
 }
 struct __attribute__((packed, aligned(1))) UnalignedPair {
     uint32_t lo, hi;
@@ -263,7 +278,7 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // UF: the path costs carry an offset of P2 and the recurrence runs in its unsigned form (SgbmGeom::uform); the volume
 // then holds T + P2 and the per-column minimum + P2.
 template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1, bool UF = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CSH2 == 3 ? 4 : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CSH2 == 3 || (CSH2 == 5 && LPP == 16)) ? 4 : 1)))
 k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
@@ -275,6 +290,22 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // the other three wait for it at the barrier.)  The first MRK rounds are unrolled with their staging index in
     // a register: all rounds of the register-ring variants, and of block sizes up to 5 otherwise.
     constexpr int MRK = (2 * (CSH2 > 0 ? CSH2 : 2) * CW + 255) / 256;
+    // The register-ring variants need little LDS, so they keep two pixel-cost tiles and alternate between them: the
+    // barrier that separated one row's tile reads from the next row's tile writes falls away, and the inputs of a row
+    // are put into LDS one row earlier, so that the one remaining barrier of a row publishes them together with the
+    // tile.  The box sums of two adjacent columns share all but one of their tile columns; the two lane groups of
+    // such a pair add half of the shared columns each and swap the halves (PAIRBOX).
+#ifndef L3D_V_ONEBAR
+#define L3D_V_ONEBAR 1
+#endif
+#ifndef L3D_V_PAIRBOX
+#define L3D_V_PAIRBOX 1
+#endif
+#ifndef L3D_V_PAIRSPLIT
+#define L3D_V_PAIRSPLIT 1
+#endif
+    constexpr bool ONEBAR = CSH2 > 0 && L3D_V_ONEBAR;
+    constexpr bool PAIRBOX = CSH2 > 0 && L3D_V_PAIRBOX;
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x, grp = tid / LPP, l = tid & (LPP - 1);
     const bool first = l == 0, last = l == LPP - 1;
@@ -298,11 +329,12 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     const int tileC = GPB + 2 * SW2;
     const int nd = (tileC - 1 + DP + 3) / 4 + 1;    // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
-    const int cstride = vertical_copy_stride(tileC, DP);
+    const int cstride = vertical_copy_stride(tileC, DP, LPP, NP);
     const int stageW = 2 * cstride + 6 * tileC;     // = vertical_stage_words(tileC, D)
     uint32_t *stage = smem;                         // [2][ 2 copies [cstride >= 6 planes [2 * nd]] | tileC left pixels [6] ]
-    uint32_t *pixT = smem + 2 * stageW;             // [tileC][LPP][NP]
-    uint32_t *ring = pixT + tileC * LPP * NP;       // [NR][256][NP], thread-private slots
+    uint32_t *pixT0 = smem + 2 * stageW;            // [tileC][LPP][NP] (ONEBAR: two of them)
+    const int tileW = tileC * LPP * NP;
+    uint32_t *ring = pixT0 + tileW;                 // [NR][256][NP], thread-private slots (LDS-ring variants only)
     const int xa = bx * GPB;
     const int xc_own = xa + grp;
     const bool active = xc_own < W1;
@@ -389,8 +421,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // pixel costs of the row staged in `buf` -> LDS tile -> horizontal box sum for this thread's column -> ring slot.
     // Barrier A separates the previous row's tile reads from this row's tile writes (and publishes the
     // stage written since the last barrier); barrier B publishes the tile.
-    auto box_row = [&](int slot, int buf) __attribute__((always_inline)) {
-        lds_barrier();
+    auto pix_row = [&](uint32_t *pixT, int buf) __attribute__((always_inline)) {
         const uint32_t *st = stage + buf * stageW;
         {
             const uint32_t *lp = st + 2 * cstride + 6 * grp;
@@ -430,9 +461,62 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #pragma unroll 1
             for (int j = tid + 256 * MRK; j < nmargin; j += 256) margin_cost(j, margin_word(j));
         }
+    };
+    auto box_row = [&](int slot, int buf) __attribute__((always_inline)) {
+        lds_barrier();
+        pix_row(pixT0, buf);
         lds_barrier();
     };
-    auto box_sum = [&](int slot) __attribute__((always_inline)) {
+    // PAIRBOX: columns 2k and 2k + 1 of the block sit in the two lane groups that the exchange below connects (the halves
+    // of a DPP row with 8 lanes per pixel, two adjacent DPP rows with 16).  Their windows [c, c + 2 SW2] and
+    // [c + 1, c + 1 + 2 SW2] share 2 SW2 tile columns: the even group adds the first SW2 of those, the odd group the
+    // last SW2, each takes the other's partial sum, and adds the one column that is its own.  SW2 + 1 tile columns read
+    // and SW2 + 1 additions per word instead of 2 SW2 + 1 and 2 SW2 (sums of 16-bit words in any order are the same).
+    // Bank conflicts of these reads (8 lanes per pixel, a tile column = 8 * NP words, NP = 6: four columns apart is the same
+    // bank): the four groups of a half wave must read columns that differ modulo 4.  The two even groups start two columns
+    // apart and each odd group SW2 columns behind its partner, which is fine for odd SW2; for even SW2 the odd groups walk
+    // their columns rotated by one (start at the second, take the first last), which needs a second base for that last read.
+    const int pair_s = grp & 1;
+    constexpr bool PB_ROT = LPP == 8 && CSH2 > 0 && CSH2 % 2 == 0;
+    const int pb_first = grp + 1 + pair_s * (SW2 - 1);                                       // first column of this group's half
+    const uint32_t pb_part = (uint32_t)(((pb_first + (PB_ROT ? pair_s : 0)) * LPP + l) * NP);
+    const uint32_t pb_last = (uint32_t)(((pb_first + (PB_ROT ? pair_s * (1 - SW2) : 0)) * LPP + l) * NP);   // base of read SW2 - 1
+    const uint32_t pb_own = (uint32_t)(((grp + pair_s * 2 * SW2) * LPP + l) * NP);           // the column only this window holds
+    auto box_sum_pair = [&](const uint32_t *pixT) __attribute__((always_inline)) {
+        constexpr int HALF = CSH2 > 0 ? CSH2 : 1;
+        // (SPLIT: the tile columns are requested in two groups, which holds fewer of them in registers at a time)
+        constexpr int G1 = L3D_V_PAIRSPLIT ? (HALF + 1) / 2 : HALF;
+        Pack<NP> px[HALF + 1];
+#pragma unroll
+        for (int j = 0; j < G1; j++) px[j] = *reinterpret_cast<const Pack<NP> *>(pixT + (j == HALF - 1 ? pb_last : pb_part) + j * LPP * NP);
+        uint32_t a[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            a[p] = px[0].v[p];
+#pragma unroll
+            for (int j = 1; j < G1; j++) a[p] = pk_add(a[p], px[j].v[p]);
+        }
+        if (L3D_V_PAIRSPLIT) {
+            // the second group's reads stay behind the first group's additions
+#pragma unroll
+            for (int p = 0; p < NP; p++) asm volatile("" : "+v"(a[p]) : : "memory");
+        }
+#pragma unroll
+        for (int j = G1; j < HALF; j++) px[j] = *reinterpret_cast<const Pack<NP> *>(pixT + (j == HALF - 1 ? pb_last : pb_part) + j * LPP * NP);
+        px[HALF] = *reinterpret_cast<const Pack<NP> *>(pixT + pb_own);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int j = G1; j < HALF; j++) a[p] = pk_add(a[p], px[j].v[p]);
+            const uint32_t other = LPP == 8 ? dpp_row_any<DPP_ROW_ROR8>(a[p]) : (uint32_t)__builtin_amdgcn_ds_swizzle((int)a[p], 0x401f);   // lane ^ 8 / lane ^ 16
+            hs[p] = pk_add(pk_add(a[p], other), px[HALF].v[p]);
+        }
+    };
+    auto box_sum = [&](int slot, const uint32_t *pixT) __attribute__((always_inline)) {
+        if constexpr (PAIRBOX) {
+            box_sum_pair(pixT);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NP; p++) hs[p] = 0;
         // A loop that waits for each tile column exposes one LDS round trip per column: for block size 5, the common
@@ -470,7 +554,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         lds_barrier();            // the previous row's stage reads are done
         stage_put(0);
         box_row(kk % NR, 0);
-        box_sum(kk % NR);
+        box_sum(kk % NR, pixT0);
         const int scale = (k == start) ? SH2 + 1 : 1;
 #pragma unroll
         for (int p = 0; p < NP; p++) Cst[p] = pk_add(Cst[p], pk_mul(hs[p], scale));
@@ -510,7 +594,19 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     // published by barrier A of iteration y; readers of that stage buffer finished two iterations
     // earlier.  Waiting for a fetch also waits for every older store, so the wait sits a whole
     // iteration after both were issued: by then they have long completed.
-    if (start + 1 < end && start + 1 + SH2 <= H - 1) stage_fetch(start + 1 + SH2);
+    // ONEBAR: row y + 1 + SH2 is fetched during iteration y - 2, put into stage (y & 1) during iteration y - 1 (published by
+    // that iteration's barrier), turned into pixel costs in tile (y & 1) before the barrier of iteration y and box-summed
+    // after it.  Writers of a tile or stage buffer follow its last readers by at least one barrier.
+    auto row_in = [&](int y) { return (y + 1 < end) && (y + 1 + SH2 <= H - 1); };   // iteration y takes a new image row into the window
+    if constexpr (ONEBAR) {
+        if (row_in(start)) {
+            stage_fetch(start + 1 + SH2);
+            lds_barrier();                 // the reads of the first rows are done
+            stage_put(start & 1);
+            if (row_in(start + 1)) stage_fetch(start + 2 + SH2);
+            lds_barrier();
+        }
+    } else if (start + 1 < end && start + 1 + SH2 <= H - 1) stage_fetch(start + 1 + SH2);
     // Register ring (CSH2 > 0): the rows are walked in groups of RNR with the group unrolled, so that "the slot of the
     // oldest row" is a compile-time index k -- the new row's sums replace the oldest row's in place and nothing is
     // shifted (a shift register cost 2 * CSH2 * NP register moves per row and lane: 54 of ~400 instructions of the
@@ -528,8 +624,15 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         const bool fetch_next = (y + 2 < end) && (y + 2 + SH2 <= H - 1);
         if constexpr (UF) topMin = sgm_step_u<NP, LPP>(Cst, Tst, topMin, pen, first, last);
         else topMin = sgm_step<NP, LPP, PAD>(Cst, Tst, topMin, pen, first, last, pad);
-        if (box_now) stage_put(buf);
-        if (fetch_next) stage_fetch(y + 2 + SH2);
+        uint32_t *tile = pixT0 + (ONEBAR ? (y & 1) * tileW : 0);
+        if constexpr (ONEBAR) {
+            if (box_now) pix_row(tile, buf);
+            if (row_in(y + 1)) stage_put(buf ^ 1);
+            if (row_in(y + 2)) stage_fetch(y + 3 + SH2);
+        } else {
+            if (box_now) stage_put(buf);
+            if (fetch_next) stage_fetch(y + 2 + SH2);
+        }
         if (y >= first_stored && active) {
             Pack<NP> pc, pt;
 #pragma unroll
@@ -551,8 +654,9 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
             } else
                 sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
             if (box_now) {
-                box_row(slot_add, buf);
-                box_sum(slot_add);
+                if constexpr (ONEBAR) lds_barrier();
+                else box_row(slot_add, buf);
+                box_sum(slot_add, tile);
             } else if constexpr (CSH2 > 0) {
                 // below the last image row: that row again, the newest entry of the ring
 #pragma unroll

@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t dpp_row_any(uint32_t src)
 #define DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]: lane i <- lane i^2
 #define DPP_ROW_HALF_MIRROR 0x141 // lane i <- lane 7-i inside each half row
 #define DPP_ROW_MIRROR 0x140      // lane i <- lane 15-i
+#define DPP_ROW_ROR8 0x128        // lane i <- lane i^8 (rotation by half a row)
 
 // A pixel's disparity vector is spread over a group of LPP consecutive lanes (LPP = 4, 8 or 16,
 // groups aligned inside a DPP row).  All-lanes minimum over one group; every move has a source
