@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ l
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: pixel cost -> box aggregation -> top->down path, one block per (256/LPP columns, stripe, frame)
+// K2: pixel cost -> box aggregation -> top->down path, one block per (NT/LPP columns, stripe, frame), NT threads
 // ---------------------------------------------------------------------------------------------
 // Birchfield-Tomasi cost of one channel for a packed pair of disparities
 __device__ __forceinline__ uint32_t bt_pair(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1)
@@ -246,12 +246,12 @@ __host__ __device__ inline int vertical_copy_stride(int tileC, int D, int LPP, i
     return (w + 3) / 4 * 4 + 2;
 }
 __host__ __device__ inline int vertical_stage_words(int tileC, int D, int LPP, int NP) { return 2 * vertical_copy_stride(tileC, D, LPP, NP) + 6 * tileC; }
-__host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D, bool ring_in_regs = false)
+__host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D, bool ring_in_regs = false, int NT = 256)
 {
-    const int tileC = 256 / LPP + 2 * SW2;
+    const int tileC = NT / LPP + 2 * SW2;
     // (the register-ring variants keep two pixel-cost tiles and need one barrier per row)
     return 2 * (size_t)vertical_stage_words(tileC, D, LPP, NP) + (size_t)tileC * LPP * NP * (ring_in_regs ? 2 : 1) +
-           (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * 256 * NP);
+           (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * NT * NP);
 }
 struct __attribute__((packed, aligned(1))) UnalignedPair {
     uint32_t lo, hi;
@@ -277,19 +277,21 @@ constexpr int kStageLoadsMax = 3; // staging words per thread and row (host chec
 // offset of the row loop is then a compile-time constant and travels in the instructions' offset fields.
 // UF: the path costs carry an offset of P2 and the recurrence runs in its unsigned form (SgbmGeom::uform); the volume
 // then holds T + P2 and the per-column minimum + P2.
-template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1, bool UF = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CSH2 == 3 || (CSH2 == 5 && LPP == 16)) ? 4 : 1)))
+// NT: threads per block.  512 for the register-ring variants with 16 lanes per pixel: a block of 256 threads owns 16
+// columns there and computes up to 10 margin columns beside them; with 32 own columns the margin's share halves.
+template <int NP, int LPP, bool PAD, int CSH2 = 0, int BS2 = -1, bool UF = false, int NT = 256>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CSH2 == 3 || (CSH2 > 0 && LPP == 16)) ? 4 : 1)))
 k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__restrict__ rrev,
                                                        uint32_t *__restrict__ Cvol, uint32_t *__restrict__ Tvol, uint32_t *__restrict__ Mvol)
 {
-    constexpr int GPB = 256 / LPP;          // image columns per block
+    constexpr int GPB = NT / LPP;          // image columns per block
     constexpr int CW = NP * LPP;            // u32 per volume column (= D / 2)
     // The tile has 2*SW2 margin columns beyond the block's own GPB.  Their pixel costs are computed one 32-bit word
-    // (two disparities) per thread, spread over all threads of the block in rounds of 256 words.  (A second
+    // (two disparities) per thread, spread over all threads of the block in rounds of NT words.  (A second
     // whole-column pass by the first lane groups, the obvious alternative, doubles the work of the first wave, and
     // the other three wait for it at the barrier.)  The first MRK rounds are unrolled with their staging index in
     // a register: all rounds of the register-ring variants, and of block sizes up to 5 otherwise.
-    constexpr int MRK = (2 * (CSH2 > 0 ? CSH2 : 2) * CW + 255) / 256;
+    constexpr int MRK = (2 * (CSH2 > 0 ? CSH2 : 2) * CW + NT - 1) / NT;
     // The register-ring variants need little LDS, so they keep two pixel-cost tiles and alternate between them: the
     // barrier that separated one row's tile reads from the next row's tile writes falls away, and the inputs of a row
     // are put into LDS one row earlier, so that the one remaining barrier of a row publishes them together with the
@@ -334,7 +336,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     uint32_t *stage = smem;                         // [2][ 2 copies [cstride >= 6 planes [2 * nd]] | tileC left pixels [6] ]
     uint32_t *pixT0 = smem + 2 * stageW;            // [tileC][LPP][NP] (ONEBAR: two of them)
     const int tileW = tileC * LPP * NP;
-    uint32_t *ring = pixT0 + tileW;                 // [NR][256][NP], thread-private slots (LDS-ring variants only)
+    uint32_t *ring = pixT0 + tileW;                 // [NR][NT][NP], thread-private slots (LDS-ring variants only)
     const int xa = bx * GPB;
     const int xc_own = xa + grp;
     const bool active = xc_own < W1;
@@ -353,8 +355,8 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     bool s_left[kStageLoadsMax], s_on[kStageLoadsMax];
 #pragma unroll
     for (int e = 0; e < kStageLoadsMax; e++) {
-        const int i = min(tid + 256 * e, nroles - 1);
-        s_on[e] = tid + 256 * e < nroles;
+        const int i = min(tid + NT * e, nroles - 1);
+        s_on[e] = tid + NT * e < nroles;
         s_left[e] = i >= 6 * nd;
         const int w = i - 6 * nd;                    // left: tile column
         const int j = i / nd, idx = i - j * nd;      // right: plane, word
@@ -376,7 +378,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     };
     uint32_t mword[MRK];
 #pragma unroll
-    for (int r = 0; r < MRK; r++) mword[r] = margin_word(min(tid + 256 * r, max(nmargin - 1, 0)));
+    for (int r = 0; r < MRK; r++) mword[r] = margin_word(min(tid + NT * r, max(nmargin - 1, 0)));
 
     PadFlags<NP, PAD> pad;
     pad.init(l, g.D / 2);
@@ -391,7 +393,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         const char *rrow = reinterpret_cast<const char *>(rrev_b + (size_t)k * W);
 #pragma unroll
         for (int e = 0; e < kStageLoadsMax; e++) {
-            if (e * 256 < nroles && s_on[e]) {
+            if (e * NT < nroles && s_on[e]) {
                 const UnalignedPair v = *reinterpret_cast<const UnalignedPair *>((s_left[e] ? lrow : rrow) + s_goff[e]);
                 sreg_lo[e] = v.lo;
                 sreg_hi[e] = v.hi;
@@ -402,7 +404,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         uint32_t *st = stage + buf * stageW;
 #pragma unroll
         for (int e = 0; e < kStageLoadsMax; e++) {
-            if (e * 256 < nroles && s_on[e]) {
+            if (e * NT < nroles && s_on[e]) {
                 const uint32_t lo = sreg_lo[e], hi = sreg_hi[e];
                 uint32_t *o = st + s_lidx[e];
                 if (s_left[e]) {
@@ -455,11 +457,11 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         };
 #pragma unroll
         for (int r = 0; r < MRK; r++) {
-            if (tid + 256 * r < nmargin) margin_cost(tid + 256 * r, mword[r]);
+            if (tid + NT * r < nmargin) margin_cost(tid + NT * r, mword[r]);
         }
         if (CSH2 == 0) {
 #pragma unroll 1
-            for (int j = tid + 256 * MRK; j < nmargin; j += 256) margin_cost(j, margin_word(j));
+            for (int j = tid + NT * MRK; j < nmargin; j += NT) margin_cost(j, margin_word(j));
         }
     };
     auto box_row = [&](int slot, int buf) __attribute__((always_inline)) {
@@ -541,7 +543,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
             Pack<NP> o;
 #pragma unroll
             for (int p = 0; p < NP; p++) o.v[p] = hs[p];
-            *reinterpret_cast<Pack<NP> *>(ring + (slot * 256 + tid) * NP) = o;
+            *reinterpret_cast<Pack<NP> *>(ring + (slot * NT + tid) * NP) = o;
         }
     };
 
@@ -652,7 +654,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #pragma unroll
                 for (int p = 0; p < NP; p++) sub.v[p] = rr[k][p];
             } else
-                sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * 256 + tid) * NP);
+                sub = *reinterpret_cast<const Pack<NP> *>(ring + (slot_sub * NT + tid) * NP);
             if (box_now) {
                 if constexpr (ONEBAR) lds_barrier();
                 else box_row(slot_add, buf);
@@ -662,7 +664,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = rr[(k + RNR - 1) % RNR][p];
             } else {
-                const Pack<NP> o = *reinterpret_cast<const Pack<NP> *>(ring + (slot_last * 256 + tid) * NP);
+                const Pack<NP> o = *reinterpret_cast<const Pack<NP> *>(ring + (slot_last * NT + tid) * NP);
 #pragma unroll
                 for (int p = 0; p < NP; p++) hs[p] = o.v[p];
             }
@@ -1256,6 +1258,15 @@ static bool vertical_ring_in_regs(const SgbmGeom &g)
     const bool shape = g.Dp == g.D && ((g.NPv == 6 && g.LPPv == 8) || (g.NPv == 4 && g.LPPv == 16));
     return shape && g.SH2 >= 3 && g.SH2 <= 5 && g.SW2 == g.SH2;
 }
+// threads per block of the vertical kernel (see its NT parameter)
+static int vertical_threads(const SgbmGeom &g)
+{
+    if (const char *ov = std::getenv("L3D_SGBM_VERTICAL_THREADS"))
+        if (std::atoi(ov) == 256) return 256;
+    // (8 lanes per pixel at block size 7, the one other variant that fits 128 registers: 2.03 -> 2.09 ms per 128 pairs of
+    // 640x360 with 96 disparities -- 544 cost columns are 17 blocks of 32 but 8.5 of 64 -- so it keeps 256)
+    return (g.ring_regs && g.LPPv == 16) ? 512 : 256;
+}
 
 struct l3d_sgbm {
     SgbmGeom g;
@@ -1388,8 +1399,9 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         return L3D_ERR_UNSUPPORTED;
     }
     h->g.ring_regs = vertical_ring_in_regs(g) && !(std::getenv("L3D_SGBM_RING_REGS") && std::atoi(std::getenv("L3D_SGBM_RING_REGS")) == 0);
-    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.Dp, g.ring_regs != 0) * sizeof(uint32_t);
-    if (vertical_stage_roles(256 / g.LPPv + 2 * g.SW2, g.Dp) > 256 * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
+    const int vnt = vertical_threads(g);
+    h->lds_vertical = vertical_lds_words(g.LPPv, g.NPv, g.SW2, g.SH2, g.Dp, g.ring_regs != 0, vnt) * sizeof(uint32_t);
+    if (vertical_stage_roles(vnt / g.LPPv + 2 * g.SW2, g.Dp) > vnt * kStageLoadsMax || (size_t)6 * width * height >= (1ull << 31)) {
         delete h;
         set_error("l3d_sgbm_create: image %dx%d with %d disparities exceeds the input staging of the vertical kernel", width, height, g.D);
         return L3D_ERR_UNSUPPORTED;
@@ -1482,6 +1494,17 @@ static void launch_vertical_form(l3d_sgbm *h, int B, hipStream_t s)
 {
     const SgbmGeom &g = h->g;
     dim3 gv(cdiv(g.W1, 256 / LPP), 4, B);
+    if constexpr (!PAD && NP == 4 && LPP == 16) {
+        if (g.ring_regs && vertical_threads(g) == 512) {
+            const dim3 gw(cdiv(g.W1, 512 / LPP), 4, B);
+            switch (g.SH2) {
+            case 3: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 3, -1, UF, 512>), gw, dim3(512), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 4: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 4, -1, UF, 512>), gw, dim3(512), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            case 5: hipLaunchKernelGGL((k_cost_vertical<NP, LPP, PAD, 5, -1, UF, 512>), gw, dim3(512), h->lds_vertical, s, g, h->lrec, h->rrev, h->Cvol, h->Tvol, h->Mvol); return;
+            default: break;
+            }
+        }
+    }
     if constexpr (!PAD && ((NP == 6 && LPP == 8) || (NP == 4 && LPP == 16))) {
         // the block sizes with a register-ring variant (see vertical_ring_in_regs)
         if (g.ring_regs) {
