@@ -28,7 +28,15 @@
 
 namespace l3d {
 
-constexpr int DT_W = 64, DT_H = 16; // discontinuity-map tile
+#ifndef L3D_DT_H
+#define L3D_DT_H 32
+#endif
+constexpr int DT_W = 64, DT_H = L3D_DT_H; // discontinuity-map tile
+constexpr int DT_XS = 16, DT_YS = 8; // outputs a thread produces by sliding its window along a row / down a column
+#ifndef L3D_DT_LD
+#define L3D_DT_LD 13
+#endif
+constexpr int DT_LD = L3D_DT_LD;     // tile values a thread requests together (13: the whole tile of the common radius 5 in one go)
 
 __device__ __forceinline__ int wls_reflect101(int p, int n)
 {
@@ -37,53 +45,102 @@ __device__ __forceinline__ int wls_reflect101(int p, int n)
     return p;
 }
 
+// LDS of k_wls_disc in bytes: the row sums of d^2 (64-bit) and of d (int), pitch 65, and the disparity tile
+__host__ __device__ inline size_t wls_disc_lds(int r)
+{
+    const int GH = DT_H + 2 * r, GWp = ((DT_W + 2 * r) / 2 | 1) * 2;      // 16-bit entries, an odd number of words a row
+    return (size_t)GH * GWp * sizeof(int16_t) + 8 + (size_t)GH * (DT_W + 1) * (sizeof(int) + sizeof(long long));
+}
+
 // var = box(d^2) - box(d)^2 over (2r+1)^2, the sub-image extended by BORDER_REFLECT_101 (cv::boxFilter's default on the
 // float copy of the sub-image), conf = max(0, 1 - rolloff * var); box sums are exact integers, scaled by the double
 // 1 / (window area) and rounded to float once, as boxFilter's double accumulator does.
-__global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ disp, int W, int H, int x0, int rw, int r, float rolloff,
-                                                  float *__restrict__ out)
+// Both views in one launch (blockIdx.z = 2 * frame + view).  The box is two passes of running sums over a 64 x 16 tile in
+// LDS: along the rows a thread owns 16 outputs of one tile row (window start-up, then one value in and one out per
+// step), down the columns 8 outputs of one column -- about 3 LDS reads per output and pass instead of 2r + 1.  Threads
+// of a wave walk adjacent rows in the first pass (the tile's pitch is odd, so they sit on different banks) and
+// adjacent columns in the second.
+__global__ void __launch_bounds__(256) k_wls_disc(const int16_t *__restrict__ dispL, const int16_t *__restrict__ dispR, int W, int H, int xL,
+                                                  int xR, int rw, int r, float rolloff, float *__restrict__ outL, float *__restrict__ outR)
 {
     extern __shared__ int smi[];
-    const int GW = DT_W + 2 * r, GH = DT_H + 2 * r;
-    int *tile = smi;                                      // [GH][GW] disparity
-    int *h1 = tile + GH * GW;                             // [GH][DT_W] row sums of d
-    long long *h2 = reinterpret_cast<long long *>(h1 + GH * DT_W + ((GH * GW + GH * DT_W) & 1)); // [GH][DT_W] row sums of d^2
+    const int GW = DT_W + 2 * r, GH = DT_H + 2 * r, GWp = (GW / 2 | 1) * 2, HP = DT_W + 1;
+    long long *h2 = reinterpret_cast<long long *>(smi);   // [GH][HP] row sums of d^2
+    int *h1 = reinterpret_cast<int *>(h2 + GH * HP);      // [GH][HP] row sums of d
+    int16_t *tile = reinterpret_cast<int16_t *>(h1 + GH * HP);   // [GH][GWp] disparity
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * DT_W, ty0 = blockIdx.y * DT_H, b = blockIdx.z;
-    const int16_t *d = disp + (size_t)b * W * H;
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int gy = i / GW, gx = i - gy * GW;
-        const int x = wls_reflect101(tx0 - r + gx, rw), y = wls_reflect101(ty0 - r + gy, H);
-        tile[i] = d[(size_t)y * W + x0 + x];
+    const int tx0 = blockIdx.x * DT_W, ty0 = blockIdx.y * DT_H, b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int16_t *d = (side ? dispR : dispL) + (size_t)b * W * H;
+    const int x0 = side ? xR : xL;
+    float *out = side ? outR : outL;
+    // (DT_LD values a thread are requested before the first is stored: a load per turn of the loop left the block waiting
+    // for memory a dozen times in a row)
+    for (int i0 = tid; i0 < GH * GW; i0 += DT_LD * 256) {
+        int v[DT_LD], at[DT_LD];
+#pragma unroll
+        for (int k = 0; k < DT_LD; k++) {
+            const int i = min(i0 + k * 256, GH * GW - 1);
+            const int gy = i / GW, gx = i - gy * GW;
+            const int x = wls_reflect101(tx0 - r + gx, rw), y = wls_reflect101(ty0 - r + gy, H);
+            at[k] = gy * GWp + gx;
+            v[k] = d[(size_t)y * W + x0 + x];
+        }
+#pragma unroll
+        for (int k = 0; k < DT_LD; k++)
+            if (i0 + k * 256 < GH * GW) tile[at[k]] = (int16_t)v[k];
     }
     __syncthreads();
-    for (int i = tid; i < GH * DT_W; i += 256) {
-        const int gy = i / DT_W, x = i - gy * DT_W;
+    const int win = 2 * r + 1;
+    for (int i = tid; i < GH * (DT_W / DT_XS); i += 256) {
+        const int seg = i / GH, gy = i - seg * GH;
+        const int16_t *row = tile + gy * GWp + seg * DT_XS;
         int a = 0;
         long long q = 0;
-        for (int j = 0; j <= 2 * r; j++) {
-            const int v = tile[gy * GW + x + j];
+#pragma unroll 4
+        for (int j = 0; j < win; j++) {
+            const int v = row[j];
             a += v;
-            q += (long long)v * v;
+            q += (long long)(v * v);        // |v| < 2^15: the square fits 32 bits
         }
-        h1[i] = a;
-        h2[i] = q;
+        int *o1 = h1 + gy * HP + seg * DT_XS;
+        long long *o2 = h2 + gy * HP + seg * DT_XS;
+        o1[0] = a;
+        o2[0] = q;
+#pragma unroll 5
+        for (int x = 1; x < DT_XS; x++) {
+            const int vin = row[x + win - 1], vout = row[x - 1];
+            a += vin - vout;
+            q += (long long)(vin * vin) - (long long)(vout * vout);
+            o1[x] = a;
+            o2[x] = q;
+        }
     }
     __syncthreads();
-    const double scale = 1.0 / ((2 * r + 1) * (2 * r + 1));
-    for (int i = tid; i < DT_H * DT_W; i += 256) {
-        const int ty = i / DT_W, x = i - ty * DT_W;
-        if (tx0 + x >= rw || ty0 + ty >= H) continue;
+    const double scale = 1.0 / (win * win);
+    for (int i = tid; i < DT_W * (DT_H / DT_YS); i += 256) {
+        const int vs = i / DT_W, x = i - vs * DT_W;
+        const int *c1 = h1 + vs * DT_YS * HP + x;
+        const long long *c2 = h2 + vs * DT_YS * HP + x;
         long long a = 0, q = 0;
-        for (int j = 0; j <= 2 * r; j++) {
-            a += h1[(ty + j) * DT_W + x];
-            q += h2[(ty + j) * DT_W + x];
+#pragma unroll 4
+        for (int j = 0; j < win; j++) {
+            a += c1[j * HP];
+            q += c2[j * HP];
         }
-        const float m1 = (float)((double)a * scale);
-        const float m2 = (float)((double)q * scale);
-        const float var = m2 - m1 * m1;
-        const float c = 1.0f - rolloff * var;
-        out[((size_t)b * H + ty0 + ty) * rw + tx0 + x] = c > 0.0f ? c : 0.0f;
+        const bool col_ok = tx0 + x < rw;
+        float *o = out + ((size_t)b * H + ty0 + vs * DT_YS) * rw + tx0 + x;
+#pragma unroll 4
+        for (int k = 0; k < DT_YS; k++) {
+            if (k > 0) {
+                a += c1[(k + win - 1) * HP] - c1[(k - 1) * HP];
+                q += c2[(k + win - 1) * HP] - c2[(k - 1) * HP];
+            }
+            const float m1 = (float)((double)a * scale);
+            const float m2 = (float)((double)q * scale);
+            const float var = m2 - m1 * m1;
+            const float c = 1.0f - rolloff * var;
+            if (col_ok && ty0 + vs * DT_YS + k < H) o[(size_t)k * rw] = c > 0.0f ? c : 0.0f;
+        }
     }
 }
 
@@ -95,12 +152,17 @@ __global__ void __launch_bounds__(256) k_wls_conf(const int16_t *__restrict__ dL
                                                   float *__restrict__ u1, float *__restrict__ u2, float *__restrict__ cv, float *__restrict__ ch,
                                                   float *__restrict__ chT, float *__restrict__ conf_full)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread per image column: the columns outside the sub-image only get their zero in the confidence map
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= rw) return;
+    if (j >= W) return;
     const size_t img = ((size_t)b * H + y) * W;
+    const int x = j - lx0;
+    if (x < 0 || x >= rw) {
+        conf_full[img + j] = 0.0f;
+        return;
+    }
     const size_t sub = ((size_t)b * H + y) * rw;
-    const int j = lx0 + x;
     const int dl = dL[img + j];
     const int ridx = j - (dl >> 4);
     float c = 0.0f;
@@ -119,6 +181,65 @@ __global__ void __launch_bounds__(256) k_wls_conf(const int16_t *__restrict__ dL
     const float wh = (x < rw - 1) ? lut[abs(g0 - (int)guide[img + j + 1])] : 0.0f;
     if (ch) ch[sub + x] = wh;                             // row sweeps on the planes as they lie
     else chT[((size_t)b * rw + x) * H + y] = wh;          // sweeps on transposed planes
+}
+
+// k_wls_conf for shapes whose rows split into whole groups of four pixels (W, lx0 and rw multiples of 4): a thread takes
+// four adjacent pixels, reads its disparities and guide values as one 8- and two 4-byte words and stores every plane as
+// 16-byte pieces.  Same operations per pixel as k_wls_conf.
+__global__ void __launch_bounds__(256) k_wls_conf4(const int16_t *__restrict__ dL, const int16_t *__restrict__ dR,
+                                                   const uint8_t *__restrict__ guide, const float *__restrict__ lut, int W, int H, int lx0, int rx0,
+                                                   int rw, int thresh, const float *__restrict__ discL, const float *__restrict__ discR,
+                                                   float *__restrict__ u1, float *__restrict__ u2, float *__restrict__ cv, float *__restrict__ ch,
+                                                   float *__restrict__ conf_full)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int j0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (j0 >= W) return;
+    const size_t img = ((size_t)b * H + y) * W;
+    const int x0 = j0 - lx0;
+    if (x0 < 0 || x0 >= rw) {
+        *reinterpret_cast<f32x4 *>(conf_full + img + j0) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    const size_t sub = ((size_t)b * H + y) * rw;
+    const s16x4 dl4 = *reinterpret_cast<const s16x4 *>(dL + img + j0);
+    const uint32_t g4 = *reinterpret_cast<const uint32_t *>(guide + img + j0);
+    const uint32_t gd4 = (y < H - 1) ? *reinterpret_cast<const uint32_t *>(guide + img + W + j0) : 0u;
+    const int gnext = (x0 + 4 < rw) ? guide[img + j0 + 4] : 0;
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(discL + sub + x0);
+    int ridx[4];
+    int dr[4];
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ridx[k] = j0 + k - (dl4[k] >> 4);
+        const bool in = ridx[k] >= rx0 && ridx[k] < rx0 + rw;
+        dr[k] = in ? (int)dR[img + ridx[k]] : 0;
+        q[k] = in ? discR[sub + (ridx[k] - rx0)] : 0.0f;
+    }
+    f32x4 c4, p4, v4, h4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dl = dl4[k];
+        float c = 0.0f;
+        if (ridx[k] >= rx0 && ridx[k] < rx0 + rw) {
+            if (abs(dl + dr[k]) < thresh) c = a4[k] < q[k] ? a4[k] : q[k];
+        }
+        c = 255.0f * c;
+        c4[k] = c;
+        p4[k] = c * (float)dl;
+        const int g0 = (int)((g4 >> (8 * k)) & 0xffu);
+        v4[k] = (y < H - 1) ? lut[abs(g0 - (int)((gd4 >> (8 * k)) & 0xffu))] : 0.0f;
+        const int gr = k < 3 ? (int)((g4 >> (8 * k + 8)) & 0xffu) : gnext;
+        h4[k] = (x0 + k < rw - 1) ? lut[abs(g0 - gr)] : 0.0f;
+    }
+    *reinterpret_cast<f32x4 *>(u2 + sub + x0) = c4;
+    *reinterpret_cast<f32x4 *>(u1 + sub + x0) = p4;
+    *reinterpret_cast<f32x4 *>(conf_full + img + j0) = c4;
+    *reinterpret_cast<f32x4 *>(cv + sub + x0) = v4;
+    *reinterpret_cast<f32x4 *>(ch + sub + x0) = h4;
 }
 
 // out[b][c][r] = in[b][r][c] for two planes at once; 32x32 tiles through LDS
@@ -154,8 +275,23 @@ __global__ void __launch_bounds__(256) k_transpose2(const float *__restrict__ in
 // together, one chunk ahead of their use, instead of one element at a time.
 constexpr int FGS_CHUNK = 16;
 
+// filtered disparity of one pixel from the two smoothed planes: u1 / u2 rounded to int16 (cv::Mat::convertTo), NaN -> INT16_MIN
+__device__ __forceinline__ int wls_final_value(float a1, float a2)
+{
+    const float t = 1.0f / (a2 + 1e-43f);
+    const float v = a1 * t;
+    if (!(v == v)) return -32768;
+    if (v >= 32767.0f) return 32767;
+    if (v <= -32768.0f) return -32768;
+    return (int)rintf(v);
+}
+
+// FINAL: the last sweep of the filter (a vertical pass: line = column of the sub-image, element = image row).  Its back
+// substitution yields the smoothed planes' final values, which nothing reads but the division that makes the output:
+// they go straight into `out` (int16, full-image coordinates) and are not stored.
+template <bool FINAL>
 __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float *__restrict__ u2, const float *__restrict__ w,
-                                                  float *__restrict__ inter, int n, int m, float lambda)
+                                                  float *__restrict__ inter, int n, int m, float lambda, int16_t *__restrict__ out, int W, int lx0)
 {
     const int line = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
@@ -214,12 +350,18 @@ __global__ void __launch_bounds__(64) k_fgs_sweep(float *__restrict__ u1, float 
             xw[k] = ldf(ri, i); x1[k] = ldf(r1, i); x2[k] = ldf(r2, i);
         }
     };
+    int16_t *oline = FINAL ? out + (size_t)b * n * W + lx0 + line : nullptr;
     auto bwd = [&](int i, int k) __attribute__((always_inline)) {
         p1 = c1[k] - cw[k] * p1;
         p2 = c2[k] - cw[k] * p2;
-        stf(r1, i, p1);
-        stf(r2, i, p2);
+        if (FINAL)
+            oline[(size_t)i * W] = (int16_t)wls_final_value(p1, p2);
+        else {
+            stf(r1, i, p1);
+            stf(r2, i, p2);
+        }
     };
+    if (FINAL) oline[(size_t)(n - 1) * W] = (int16_t)wls_final_value(p1, p2);   // the last element keeps its value of the elimination
     if (n >= 2) load_bwd(n - 2, cw, c1, c2);
     int j0 = n - 2;
     for (; j0 - (FGS_CHUNK - 1) >= 0; j0 -= FGS_CHUNK) {
@@ -396,24 +538,15 @@ __global__ void __launch_bounds__(64) k_fgs_sweep_rows(float *__restrict__ u1, f
     }
 }
 
-__global__ void __launch_bounds__(256) k_wls_final(const float *__restrict__ u1, const float *__restrict__ u2, int W, int H, int lx0, int rw,
-                                                   int fill, int16_t *__restrict__ out)
+// the columns of the output outside the sub-image (all of them when there is no sub-image): the fill value
+__global__ void __launch_bounds__(256) k_wls_outside(int W, int H, int lx0, int rw, int fill, int16_t *__restrict__ out)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int no = W - rw;                                  // columns outside, per row
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= W) return;
-    int iv = fill;
-    const int xs = x - lx0;
-    if (xs >= 0 && xs < rw) {
-        const size_t sub = ((size_t)b * H + y) * rw + xs;
-        const float t = 1.0f / (u2[sub] + 1e-43f);
-        const float v = u1[sub] * t;
-        if (!(v == v)) iv = -32768;
-        else if (v >= 32767.0f) iv = 32767;
-        else if (v <= -32768.0f) iv = -32768;
-        else iv = (int)rintf(v);
-    }
-    out[((size_t)b * H + y) * W + x] = (int16_t)iv;
+    if (i >= no) return;
+    const int x = i < lx0 ? i : i + rw;
+    out[((size_t)b * H + y) * W + x] = (int16_t)fill;
 }
 
 __global__ void __launch_bounds__(256) k_fill_f32(float *p, size_t n, float v)
@@ -503,6 +636,8 @@ extern "C" int l3d_wls_create(const l3d_wls_params *p, int width, int height, in
         for (int i = 0; i < 256; i++) lut[i] = (float)(-std::exp(-std::sqrt((double)(i * i)) / (float)p->sigma_color));
         e = hipMemcpy(h->lut, lut.data(), 256 * sizeof(float), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && wls_disc_lds(p->disc_radius) > 64 * 1024)
+        e = hipFuncSetAttribute((const void *)k_wls_disc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wls_disc_lds(p->disc_radius));
     if (e != hipSuccess) {
         set_error("l3d_wls_create: %s", hipGetErrorString(e));
         l3d_wls_destroy(h);
@@ -518,14 +653,16 @@ static int wls_run(l3d_wls *h, const int16_t *dL, const int16_t *dR, const uint8
     h->last_batch = B;
     const int fill = 16 * (h->p.min_disparity - 1);
     const size_t npx = (size_t)B * W * H;
-    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, h->conf, npx, 0.0f);
+    if (rw <= 0) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, h->conf, npx, 0.0f);
     if (rw > 0) {
-        const int GW = DT_W + 2 * r, GH = DT_H + 2 * r;
-        const size_t lds = (size_t)(GH * GW + GH * DT_W + 1) * sizeof(int) + (size_t)GH * DT_W * sizeof(long long);
-        dim3 gd(cdiv(rw, DT_W), cdiv(H, DT_H), B);
-        hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dL, W, H, h->lx0, rw, r, h->p.disc_rolloff, h->discL);
-        hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), lds, s, dR, W, H, h->rx0, rw, r, h->p.disc_rolloff, h->discR);
-        hipLaunchKernelGGL(k_wls_conf, dim3(cdiv(rw, 256), H, B), dim3(256), 0, s, dL, dR, guide, h->lut, W, H, h->lx0, h->rx0, rw,
+        dim3 gd(cdiv(rw, DT_W), cdiv(H, DT_H), 2 * B);
+        hipLaunchKernelGGL(k_wls_disc, gd, dim3(256), wls_disc_lds(r), s, dL, dR, W, H, h->lx0, h->rx0, rw, r, h->p.disc_rolloff, h->discL, h->discR);
+        // (four pixels a thread when rows split into whole groups of four and the caller's maps are aligned for it)
+        if (h->rows && W % 4 == 0 && h->lx0 % 4 == 0 && (uintptr_t)dL % 8 == 0 && (uintptr_t)guide % 4 == 0 && !std::getenv("L3D_WLS_CONF1"))
+            hipLaunchKernelGGL(k_wls_conf4, dim3(cdiv(W / 4, 256), H, B), dim3(256), 0, s, dL, dR, guide, h->lut, W, H, h->lx0, h->rx0, rw,
+                               h->p.lrc_thresh, h->discL, h->discR, h->u1, h->u2, h->cv, h->ch, h->conf);
+        else
+        hipLaunchKernelGGL(k_wls_conf, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, dL, dR, guide, h->lut, W, H, h->lx0, h->rx0, rw,
                            h->p.lrc_thresh, h->discL, h->discR, h->u1, h->u2, h->cv, h->ch, h->chT, h->conf);
         float lambda = (float)h->p.lambda;
         const dim3 tg_fwd(cdiv(rw, 32), cdiv(H, 32), B), tg_bwd(cdiv(H, 32), cdiv(rw, 32), B);
@@ -535,15 +672,19 @@ static int wls_run(l3d_wls *h, const int16_t *dL, const int16_t *dR, const uint8
                 hipLaunchKernelGGL(k_fgs_sweep_rows, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->u1, h->u2, h->ch, h->inter, rw, H, lambda);
             else {
                 hipLaunchKernelGGL(k_transpose2, tg_fwd, dim3(256), 0, s, h->u1, h->u2, H, rw, h->t1, h->t2);
-                hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->t1, h->t2, h->chT, h->inter, rw, H, lambda);
+                hipLaunchKernelGGL(k_fgs_sweep<false>, dim3(cdiv(H, 64), B), dim3(64), 0, s, h->t1, h->t2, h->chT, h->inter, rw, H, lambda, nullptr, 0, 0);
                 hipLaunchKernelGGL(k_transpose2, tg_bwd, dim3(256), 0, s, h->t1, h->t2, rw, H, h->u1, h->u2);
             }
-            // vertical pass: rw lines of length H
-            hipLaunchKernelGGL(k_fgs_sweep, dim3(cdiv(rw, 64), B), dim3(64), 0, s, h->u1, h->u2, h->cv, h->inter, H, rw, lambda);
+            // vertical pass: rw lines of length H; the last one writes the output
+            if (it + 1 < h->p.fgs_iters)
+                hipLaunchKernelGGL(k_fgs_sweep<false>, dim3(cdiv(rw, 64), B), dim3(64), 0, s, h->u1, h->u2, h->cv, h->inter, H, rw, lambda, nullptr, 0, 0);
+            else
+                hipLaunchKernelGGL(k_fgs_sweep<true>, dim3(cdiv(rw, 64), B), dim3(64), 0, s, h->u1, h->u2, h->cv, h->inter, H, rw, lambda, out, W, h->lx0);
             lambda *= h->p.fgs_attenuation;
         }
     }
-    hipLaunchKernelGGL(k_wls_final, dim3(cdiv(W, 256), H, B), dim3(256), 0, s, h->u1, h->u2, W, H, h->lx0, std::max(rw, 0), fill, out);
+    if (W - std::max(rw, 0) > 0)
+        hipLaunchKernelGGL(k_wls_outside, dim3(cdiv(W - std::max(rw, 0), 256), H, B), dim3(256), 0, s, W, H, h->lx0, std::max(rw, 0), fill, out);
     L3D_HIP_CHECK(hipGetLastError());
     return L3D_OK;
 }
