@@ -120,6 +120,14 @@ def plan_frames(config, batch, rank, world):
     return B, parallel.shard_indices(B * world, rank, world), "weak", f"frames x{world}"
 
 
+def under_profiler(environ=os.environ):
+    """True when a ROCm profiler has been preloaded into this process (rocprofv3 sets ROCPROF* / ROCP_* variables and
+    LD_PRELOAD): the GPU is then initialised before Python starts, so this process must not start other programs, and
+    it does not fork workers either."""
+    pre = environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in environ)
+
+
 def _pair_job(job):
     from laser_3d_reconstruction_amd.utils import synthetic as S
 
@@ -133,6 +141,8 @@ def host_frames(W, H, D, frame_ids):
     import multiprocessing as mp
 
     workers = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16") or 16), os.cpu_count() or 1, len(frame_ids)))
+    if under_profiler():
+        workers = 1
     jobs = [(W, H, D, k) for k in frame_ids]
     if workers > 1:
         try:
@@ -291,10 +301,11 @@ def main(argv=None):
     # The other workloads first, as child processes of their own (this process has not touched the GPU yet), then the
     # CPU leg and the synthetic frames, whose worker processes are forked: all before this process holds a GPU.
     also = None
-    if rank == 0 and world == 1 and "WORLD_SIZE" not in os.environ and args.config == "C2" and args.sgbm_mode == 2 and not args.no_also:
+    if (rank == 0 and world == 1 and "WORLD_SIZE" not in os.environ and args.config == "C2" and args.sgbm_mode == 2 and not args.no_also
+            and not under_profiler()):
         also = also_configs()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sgbm_mode == 2:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sgbm_mode == 2 and not under_profiler():
         try:
             cpu = cpu_baseline(W, H, D, block, use_wls, lam, sigma, want_xyz)
         except Exception as e:

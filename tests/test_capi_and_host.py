@@ -365,6 +365,9 @@ def test_bench_launcher_plumbing(monkeypatch):
     l, r_ = bench.host_frames(96, 40, 16, [5, 2, 9])
     assert l.shape == (3, 40, 96, 3) and np.array_equal(l[1], S.stereo_pair(96, 40, 16, 2)[0]) and np.array_equal(r_[2], S.stereo_pair(96, 40, 16, 9)[1])
     assert bench.alg_bytes(640, 360, 64, False, 0)[1] == 4 * 640 * 360 * 65 + 9 * 640 * 360      # Z-only depth: 6 bytes a pixel
+    # under a preloaded profiler the process neither starts other programs nor forks workers
+    assert not bench.under_profiler({"LD_PRELOAD": "/some/other/lib.so"})
+    assert bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"}) and bench.under_profiler({"ROCPROF_OUTPUT_PATH": "x"})
     assert bench.alg_bytes(640, 360, 64, False, 0, xyz=True)[1] == 4 * 640 * 360 * 65 + 19 * 640 * 360
 
 
