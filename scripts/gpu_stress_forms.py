@@ -3,7 +3,9 @@
 Random sizes, disparity ranges, block sizes, penalties and image statistics; for each case the disparity of
   * the unsigned form of the recurrence (default where it applies) and the signed form (L3D_SGBM_UFORM=0),
   * the path-only layout and the layout with both volumes (L3D_SGBM_TONLY=0),
-  * a single-frame handle and a batch handle (other lane-group shapes)
+  * a single-frame handle and a batch handle (other lane-group shapes),
+  * the vertical kernel with its ring of box-sum rows in LDS instead of registers (L3D_SGBM_RING_REGS=0: the older row loop with two
+    barriers and unshared box sums) and with 256-thread blocks (L3D_SGBM_VERTICAL_THREADS=256)
 must be identical.  With a third argument N the first N cases (kept small) are also compared with the CPU restatement.
 usage: python scripts/gpu_stress_forms.py [cases] [seed] [cases checked against the oracle]
 """
@@ -36,6 +38,20 @@ def image_pair(rng, W, H, kind):
     return np.ascontiguousarray(a, dtype=np.uint8), np.ascontiguousarray(b, dtype=np.uint8)
 
 
+ENV_KEYS = ("L3D_SGBM_UFORM", "L3D_SGBM_TONLY", "L3D_SGBM_RING_REGS", "L3D_SGBM_VERTICAL_THREADS")
+
+
+def write_summary(name, record):
+    """Adds this run's result to the JSON file named by L3D_STRESS_SUMMARY (one entry per script and seed)."""
+    import json
+    path = os.environ.get("L3D_STRESS_SUMMARY")
+    if not path:
+        return
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data.setdefault(name, []).append(record)
+    json.dump(data, open(path, "w"), indent=1)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -46,6 +62,8 @@ def main():
     for case in range(n):
         D = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 192, 256]))
         b = int(rng.choice([1, 3, 5, 5, 7, 9, 11, 13, 15]))
+        if rng.random() < 0.25:   # the shapes with a register-ring variant of the vertical kernel
+            D, b = int(rng.choice([96, 128])), int(rng.choice([7, 9, 11]))
         big = rng.random() < 0.05 and case >= n_oracle
         W = D + int(rng.integers(4, 1200 if big else 300))
         H = int(rng.integers(b + 2, 500 if big else 120))
@@ -61,8 +79,9 @@ def main():
         gl, gr = image_pair(rng, W, H, int(rng.integers(0, 4)))
         outs = {}
         for name, env, batch in [("default", {}, 1), ("signed", {"L3D_SGBM_UFORM": "0"}, 1), ("two-volume", {"L3D_SGBM_TONLY": "0"}, 1),
-                                 ("batch", {}, 5), ("batch-signed", {"L3D_SGBM_UFORM": "0"}, 5)]:
-            for k in ("L3D_SGBM_UFORM", "L3D_SGBM_TONLY"):
+                                 ("batch", {}, 5), ("batch-signed", {"L3D_SGBM_UFORM": "0"}, 5),
+                                 ("ring-in-lds", {"L3D_SGBM_RING_REGS": "0"}, 1), ("256-threads", {"L3D_SGBM_VERTICAL_THREADS": "256"}, 5)]:
+            for k in ENV_KEYS:
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:
@@ -88,11 +107,16 @@ def main():
             if not same:
                 bad += 1
                 print(f"MISMATCH case {case} route {name}: W={W} H={H} {kw}", flush=True)
-        if case % 500 == 499:
+        if case % 100 == 99:
             print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-    for k in ("L3D_SGBM_UFORM", "L3D_SGBM_TONLY"):
+    for k in ENV_KEYS:
         os.environ.pop(k, None)
     print(f"done: {n} cases, {computed} computed, {bad} mismatches; refused: {errors}")
+    write_summary("matcher_routes", {"script": "scripts/gpu_stress_forms.py", "seed": int(sys.argv[2]) if len(sys.argv) > 2 else 1, "cases": n,
+                                     "computed": computed, "compared_with_cpu_restatement": min(n_oracle, n), "mismatches": bad,
+                                     "routes": ["default", "signed recurrence", "two-volume layout", "batch handle", "batch handle, signed",
+                                                "box-sum ring in LDS", "256-thread blocks"],
+                                     "refused_shapes": errors, "seconds": round(time.time() - t0)})
     return 1 if bad else 0
 
 

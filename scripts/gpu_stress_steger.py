@@ -37,6 +37,17 @@ def image(rng, W, H, ch, kind):
     return np.ascontiguousarray(np.stack([g, np.clip(g.astype(int) + rng.integers(-3, 4, g.shape), 0, 255).astype(np.uint8), g], -1))
 
 
+def write_summary(name, record):
+    """Adds this run's result to the JSON file named by L3D_STRESS_SUMMARY (one entry per script and seed)."""
+    import json
+    path = os.environ.get("L3D_STRESS_SUMMARY")
+    if not path:
+        return
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data.setdefault(name, []).append(record)
+    json.dump(data, open(path, "w"), indent=1)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -62,6 +73,9 @@ def main():
         if case % 50 == 49:
             print(f"{case + 1} cases, {pts} points, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     print(f"done: {n} cases, {pts} points, {bad} mismatches")
+    write_summary("steger_extractor", {"script": "scripts/gpu_stress_steger.py", "seed": int(sys.argv[2]) if len(sys.argv) > 2 else 1, "cases": n,
+                                       "points": int(pts), "mismatches": bad, "compared": "point count and coordinates (1e-3 px) against the CPU "
+                                       "restatement, every image", "seconds": round(time.time() - t0)})
     return 1 if bad else 0
 
 

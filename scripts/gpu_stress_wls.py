@@ -14,6 +14,17 @@ from laser_3d_reconstruction_amd import stereo  # noqa: E402
 from laser_3d_reconstruction_amd.utils import synthetic as S  # noqa: E402
 
 
+def write_summary(name, record):
+    """Adds this run's result to the JSON file named by L3D_STRESS_SUMMARY (one entry per script and seed)."""
+    import json
+    path = os.environ.get("L3D_STRESS_SUMMARY")
+    if not path:
+        return
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data.setdefault(name, []).append(record)
+    json.dump(data, open(path, "w"), indent=1)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -59,6 +70,10 @@ def main():
             print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     os.environ.pop("L3D_WLS_TRANSPOSE", None)
     print(f"done: {n} cases ({rows_route} with a sub-image width that takes the row sweeps), {bad} mismatches")
+    write_summary("smoother_routes", {"script": "scripts/gpu_stress_wls.py", "seed": int(sys.argv[2]) if len(sys.argv) > 2 else 1, "cases": n,
+                                      "on_row_sweep_route": int(rows_route), "compared_with_cpu_restatement": min(n_oracle, n), "mismatches": bad,
+                                      "compared": "filtered disparity and confidence map, row-sweep route (four-pixel confidence kernel) against "
+                                                  "transposing route (one-pixel confidence kernel)", "seconds": round(time.time() - t0)})
     return 1 if bad else 0
 
 
