@@ -236,21 +236,29 @@ __host__ __device__ inline int vertical_stage_roles(int tileC, int D) { return 6
 // distinct words a half wave requests, for every displacement modulo 32; a stride of 3, 5, 7 words on 8 lanes has no
 // conflict-free displacement.)  With the rule of NP = 4 applied to NP = 6 every read of the staged planes took two
 // LDS cycles: two fifths of the kernel's LDS cycles at 96 disparities were bank conflicts.
-__host__ __device__ inline int vertical_copy_stride(int tileC, int D, int LPP, int NP)
+// `swz`: the variant that swaps word pairs inside every second block of 32 words of a staged plane (see SWZ in the
+// kernel): its planes are two words longer and its copies an odd number of words apart.
+__host__ __device__ inline int vertical_copy_stride(int tileC, int D, int LPP, int NP, bool swz = false)
 {
-    const int w = 12 * ((tileC - 1 + D + 3) / 4 + 1);
+    const int w = 6 * (2 * ((tileC - 1 + D + 3) / 4 + 1) + (swz ? 2 : 0));
+    if (swz) return w | 1;
     const bool want16 = LPP == 8 ? (NP == 2 || NP == 6) : (NP % 2 == 1);
     const bool want_odd = LPP == 16 && (NP == 2 || NP == 6);
     if (want16) return (w + 15) / 32 * 32 + 16;
     if (want_odd) return w | 1;
     return (w + 3) / 4 * 4 + 2;
 }
-__host__ __device__ inline int vertical_stage_words(int tileC, int D, int LPP, int NP) { return 2 * vertical_copy_stride(tileC, D, LPP, NP) + 6 * tileC; }
+__host__ __device__ inline int vertical_stage_words(int tileC, int D, int LPP, int NP, bool swz = false)
+{
+    return 2 * vertical_copy_stride(tileC, D, LPP, NP, swz) + 6 * tileC;
+}
+__host__ __device__ inline bool vertical_stage_swizzled(int LPP, int NP, bool ring_in_regs) { return ring_in_regs && LPP == 16 && NP == 4; }
 __host__ __device__ inline size_t vertical_lds_words(int LPP, int NP, int SW2, int SH2, int D, bool ring_in_regs = false, int NT = 256)
 {
     const int tileC = NT / LPP + 2 * SW2;
     // (the register-ring variants keep two pixel-cost tiles and need one barrier per row)
-    return 2 * (size_t)vertical_stage_words(tileC, D, LPP, NP) + (size_t)tileC * LPP * NP * (ring_in_regs ? 2 : 1) +
+    return 2 * (size_t)vertical_stage_words(tileC, D, LPP, NP, vertical_stage_swizzled(LPP, NP, ring_in_regs)) +
+           (size_t)tileC * LPP * NP * (ring_in_regs ? 2 : 1) +
            (ring_in_regs ? 0 : (size_t)(2 * SH2 + 1) * NT * NP);
 }
 struct __attribute__((packed, aligned(1))) UnalignedPair {
@@ -306,6 +314,16 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #ifndef L3D_V_PAIRSPLIT
 #define L3D_V_PAIRSPLIT 1
 #endif
+#ifndef L3D_V_SWZ
+#define L3D_V_SWZ 1
+#endif
+    // SWZ (16 lanes per pixel, 4 words a lane): the 16 lanes of a group read words 4 apart, i.e. 64 words over 32 banks --
+    // lanes l and l + 8 meet on a bank whatever the displacement of the copies.  Inside every second block of 32 words
+    // of a staged plane the two word pairs of each group of four change places (index ^ 2): lanes 8 apart then differ by
+    // 2 banks modulo 4, a group covers two residues modulo 4, and with the copies an odd number of words apart the
+    // other group of the half wave covers the other two.  A lane's four words are no longer consecutive, so it keeps an
+    // address for each.
+    constexpr bool SWZ = CSH2 > 0 && LPP == 16 && NP == 4 && L3D_V_SWZ;
     constexpr bool ONEBAR = CSH2 > 0 && L3D_V_ONEBAR;
     constexpr bool PAIRBOX = CSH2 > 0 && L3D_V_PAIRBOX;
     extern __shared__ uint32_t smem[];
@@ -331,8 +349,10 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
     const int tileC = GPB + 2 * SW2;
     const int nd = (tileC - 1 + DP + 3) / 4 + 1;    // u32 words per staged right-image plane
     const int nroles = 6 * nd + tileC;              // = vertical_stage_roles(tileC, D)
-    const int cstride = vertical_copy_stride(tileC, DP, LPP, NP);
+    const int PP = 2 * nd + (SWZ ? 2 : 0);          // words between the staged planes of a copy
+    const int cstride = vertical_copy_stride(tileC, DP, LPP, NP, SWZ);
     const int stageW = 2 * cstride + 6 * tileC;     // = vertical_stage_words(tileC, D)
+    auto swz = [](int t) { return SWZ ? (t ^ (((t >> 5) & 1) << 1)) : t; };   // word index inside a staged plane -> its place
     uint32_t *stage = smem;                         // [2][ 2 copies [cstride >= 6 planes [2 * nd]] | tileC left pixels [6] ]
     uint32_t *pixT0 = smem + 2 * stageW;            // [tileC][LPP][NP] (ONEBAR: two of them)
     const int tileW = tileC * LPP * NP;
@@ -360,21 +380,24 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
         s_left[e] = i >= 6 * nd;
         const int w = i - 6 * nd;                    // left: tile column
         const int j = i / nd, idx = i - j * nd;      // right: plane, word
-        s_lidx[e] = s_left[e] ? (uint32_t)(2 * cstride + 6 * w) : (uint32_t)(2 * i); // the second copy lies cstride words further
+        s_lidx[e] = s_left[e] ? (uint32_t)(2 * cstride + 6 * w) : (uint32_t)(j * PP + swz(2 * idx)); // the second copy lies cstride words further
         s_goff[e] = s_left[e] ? (uint32_t)tile_x(w) * (uint32_t)sizeof(uint2) : (uint32_t)((size_t)j * plane) + (uint32_t)(rr_lo + 4 * idx);
     }
     // byte offset inside a staged plane of the first disparity a lane needs for a tile column, as a word index into
     // the stage: copy (offset & 1), word (offset >> 1)
-    auto stage_word = [&](int c, int lane) {
+    auto stage_word = [&](int c, int lane, int wofs) {
         const int o = x_hi - tile_x(c) + lane * 2 * NP;
-        return (uint32_t)((o & 1) * cstride + (o >> 1));
+        return (uint32_t)((o & 1) * cstride + swz((o >> 1) + wofs));
     };
-    const uint32_t qword = stage_word(grp, l);
+    // (SWZ: an address per word; otherwise the words follow the first)
+    uint32_t qword[SWZ ? NP : 1];
+#pragma unroll
+    for (int w = 0; w < (SWZ ? NP : 1); w++) qword[w] = stage_word(grp, l, w);
     // margin word j = word j of the tile behind the block's own columns: (tile column GPB + j / CW, lane, word)
     const int nmargin = 2 * SW2 * CW;
     auto margin_word = [&](int j) {
         const int ch = j / CW, rem = j - ch * CW, lane = rem / NP;
-        return stage_word(GPB + ch, lane) + (uint32_t)(rem - lane * NP);
+        return stage_word(GPB + ch, lane, rem - lane * NP);
     };
     uint32_t mword[MRK];
 #pragma unroll
@@ -432,7 +455,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
 #pragma unroll
             for (int j = 0; j < 6; j++) {
 #pragma unroll
-                for (int w = 0; w < NP; w++) q[j][w] = st[j * 2 * nd + qword + w];
+                for (int w = 0; w < NP; w++) q[j][w] = st[j * PP + (SWZ ? qword[SWZ ? w : 0] : qword[0] + w)];
             }
             Pack<NP> px;
 #pragma unroll
@@ -449,7 +472,7 @@ k_cost_vertical(SgbmGeom g, const uint2 *__restrict__ lrec, const uint8_t *__res
             const uint32_t u = lp[0], u0 = lp[1], u1 = lp[2], t = lp[3], t0 = lp[4], t1 = lp[5];
             uint32_t q[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) q[k] = st[k * 2 * nd + mw];
+            for (int k = 0; k < 6; k++) q[k] = st[k * PP + mw];
             const uint32_t cg = bt_pair(u, u0, u1, q[0], q[1], q[2]);
             const uint32_t ci = bt_pair(t, t0, t1, q[3], q[4], q[5]);
             const v2u two = {2, 2};
