@@ -1498,6 +1498,17 @@ static void sobel3_f32(const float *src, int W, int H, int xorder, float *tmp, f
         }
 }
 
+/* cv2.Sobel(src_f32, CV_32F, dx, dy, ksize=3) with (dx, dy) = (1, 0) or (0, 1), exported for the golden-vector generator
+ * (tests/golden/make_improved_steger_golden.py), which runs the reference's own per-pixel code on these images. */
+ORC_API int orc_sobel3_f32(const float *src, int W, int H, int xorder, float *dst)
+{
+    float *tmp = (float *)malloc((size_t)W * H * sizeof(float));
+    if (!tmp) return -1;
+    sobel3_f32(src, W, H, xorder, tmp, dst);
+    free(tmp);
+    return 0;
+}
+
 /* variant 1: every accepted pixel (raster order); variant 2: the accepted pixel of largest |eigenvalue| per row
  * (first one on ties), y = row; variant 3: as 2 but only |offset_x| <= 0.5 is tested and candidates are the
  * pixels of `mask`.  gray8: brightness image (test gray8 > threshold; ignored when mask is given).

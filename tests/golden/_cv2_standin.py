@@ -102,7 +102,8 @@ def make_cv2_standin():
             lib.orc_fill_contour(O._p(pts, C.c_int), len(pts), w, h, O._p(img, C.c_uint8), int(color))
         return img
 
-    def GaussianBlur(src, ksize, sx, sy):
+    def GaussianBlur(src, ksize, sx, sy=None):
+        sy = sx if sy is None else sy
         assert tuple(ksize) == (0, 0) and sx == sy and src.dtype == np.float32
         src = np.ascontiguousarray(src)
         h, w = src.shape
@@ -127,7 +128,15 @@ def make_cv2_standin():
                 acc = (acc + k[r, c] * src[np.ix_(yy, xx)]).astype(np.float32)
         return acc
 
-    for f in (cvtColor, inRange, threshold, bitwise_and, morphologyEx, findContours, contourArea, drawContours, GaussianBlur, filter2D):
+    def Sobel(src, ddepth, dx, dy, ksize=3):
+        assert ddepth == cv2.CV_32F and ksize == 3 and (dx, dy) in ((1, 0), (0, 1)) and src.dtype == np.float32
+        src = np.ascontiguousarray(src)
+        h, w = src.shape
+        dst = np.empty_like(src)
+        assert lib.orc_sobel3_f32(O._p(src, C.c_float), w, h, int(dx == 1), O._p(dst, C.c_float)) == 0
+        return dst
+
+    for f in (cvtColor, inRange, threshold, bitwise_and, morphologyEx, findContours, contourArea, drawContours, GaussianBlur, filter2D, Sobel):
         setattr(cv2, f.__name__, f)
     return cv2
 
