@@ -20,6 +20,8 @@ import io
 import os
 import sys
 
+sys.dont_write_bytecode = True   # importing the reference must not leave a bytecode cache beside its sources
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -17,6 +17,8 @@ import importlib.util
 import io
 import os
 import sys
+
+sys.dont_write_bytecode = True   # importing the reference must not leave a bytecode cache beside its sources
 import types
 
 import numpy as np

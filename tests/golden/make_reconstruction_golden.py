@@ -16,6 +16,8 @@ import io
 import json
 import os
 import sys
+
+sys.dont_write_bytecode = True   # importing the reference must not leave a bytecode cache beside its sources
 import types
 
 import numpy as np
