@@ -241,7 +241,10 @@ class SingleUSBStereoCameraManager:
         gr = ops.bgr2gray_device(R) if R.dim() == 4 else R
         return self._depth_on_device(gl, gr)[0].cpu().numpy()
 
-    def get_frames(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+    def get_frames_device(self):
+        """The next frame as CUDA tensors: (rectified left image (1,H,W,3) or (1,H,W) uint8, depth map (1,H,W) float32),
+        or (None, None) when no frame can be read.  What get_frames downloads; a caller that goes on working on the
+        device (laser extractor, back-projection) starts from here."""
         if self.cap is None or not self.cap.isOpened():
             return None, None
         ret, frame = self.cap.read()
@@ -252,10 +255,15 @@ class SingleUSBStereoCameraManager:
                 or (frame.shape[0] if self.split_mode == 'horizontal' else frame.shape[0] // 2) != self.single_height):
             left_img, right_img = self._split_frame(frame)
             left_rectified, right_rectified = self.rectify_pair(left_img, right_img)
-            return left_rectified, self.compute_depth(left_rectified, right_rectified)
+            if left_rectified.shape != right_rectified.shape or left_rectified.dtype != np.uint8 or right_rectified.dtype != np.uint8:
+                raise ValueError("get_frames expects the two eyes as uint8 images of one shape")
+            L, R = self._upload(left_rectified)[None], self._upload(right_rectified)[None]
+            gl = ops.bgr2gray_device(L) if L.dim() == 4 else L
+            gr = ops.bgr2gray_device(R) if R.dim() == 4 else R
+            return L, self._depth_on_device(gl, gr)
         # The combined frame is uploaded once; each eye is remapped straight out of it (the right eye starts half a
         # row, or half a frame, further on), the gray planes come out of the remap, and only the rectified left
-        # image and the depth map are downloaded (reference :312-357).
+        # image and the depth map are kept (reference :312-357).
         F = self._upload(frame)[None]
         fh, fw, ch = frame.shape
         w, h = self.single_width, self.single_height
@@ -263,8 +271,13 @@ class SingleUSBStereoCameraManager:
         view = dict(row_stride=fw * ch, img_stride=fh * fw * ch, src_size=(w, h))
         left_rect, gl = self.rectifier_left.remap_device(F, want_bgr=True, want_gray=True, **view)
         _, gr = self.rectifier_right.remap_device(F, want_bgr=False, want_gray=True, offset_bytes=right_off, **view)
-        depth = self._depth_on_device(gl, gr)
-        return left_rect[0].cpu().numpy(), depth[0].cpu().numpy()
+        return left_rect, self._depth_on_device(gl, gr)
+
+    def get_frames(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        left, depth = self.get_frames_device()
+        if left is None:
+            return None, None
+        return left[0].cpu().numpy(), depth[0].cpu().numpy()
 
     def get_camera_intrinsics(self) -> Optional[Dict]:
         if self.camera_matrix_left is None:

@@ -1,0 +1,157 @@
+"""LaserReconstructionSystem: the reference's per-frame loop body (main.py:37-233) on the GPU.
+
+``initialize`` builds the same four components from the same ``Config`` knobs (main.py:51-162): the camera manager
+(without the Config, so the matcher follows the reference's width rule), the laser extractor chosen by
+``LASER_EXTRACTOR_TYPE``, a ``Reconstructor`` on the rectified intrinsics with ``LASER_PLANE_COEFFICIENTS`` /
+``USE_REFRACTION_CORRECTION``, and the point-cloud processor.  ``process_frame`` is main.py:164-189: frame -> rectified
+left image + depth map -> laser centre line -> 3-D points through the depth map -> rows without NaN appended to
+``point_cloud``.  Between those stages nothing leaves the device here: the combined camera frame is uploaded once, the
+extractor reads the rectified left image where the remap kernel left it, the back-projection reads the depth map where
+the depth kernel left it, and the three return values plus the new 3-D points are downloaded at the end.
+
+Differences a caller can see: frames come from ``frame_source`` (an object with ``isOpened() / read() / release()``;
+camera capture is outside the accelerated path); the console window of ``run_realtime`` (cv2.imshow, key handling:
+main.py:235-343) is not mirrored -- ``run`` below is its loop without the display.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import List, Optional
+
+import numpy as np
+
+from .camera.single_usb_stereo_camera import SingleUSBStereoCameraManager
+from .config import Config
+from .core.laser_extractor import FastStegerExtractor, SimpleLaserExtractor, _as_tuples
+from .core.reconstruction import Reconstructor
+from .utils.point_cloud import PointCloudProcessor
+
+
+class LaserReconstructionSystem:
+    def __init__(self, config=None, frame_source=None, device: int = 0, verbose: bool = False):
+        self.config = config or Config()
+        self.frame_source = frame_source
+        self.device = device
+        self.verbose = verbose
+        self.camera: Optional[SingleUSBStereoCameraManager] = None
+        self.laser_extractor = None
+        self.reconstructor: Optional[Reconstructor] = None
+        self.point_cloud_processor: Optional[PointCloudProcessor] = None
+        self.point_cloud: List[List[float]] = []
+        self.frame_count = 0
+        self.start_time = None
+        self.show_depth = True
+
+    def _log(self, msg):
+        if self.verbose:
+            print(msg)
+
+    def initialize(self, camera_id=None, width=None, height=None) -> bool:
+        cfg = self.config
+        camera_id = camera_id if camera_id is not None else cfg.SINGLE_USB_CAMERA_ID
+        width = width or cfg.CAMERA_WIDTH
+        height = height or cfg.CAMERA_HEIGHT
+        try:
+            self.camera = SingleUSBStereoCameraManager(camera_id=camera_id, width=width, height=height, fps=cfg.CAMERA_FPS,
+                                                       split_mode=cfg.SPLIT_MODE, calibration_file=cfg.STEREO_CALIBRATION_FILE,
+                                                       device=self.device, frame_source=self.frame_source, verbose=self.verbose)
+            if not self.camera.initialize():
+                self._log("camera initialisation failed")
+                return False
+        except Exception as e:
+            self._log(f"camera initialisation error: {e}")
+            return False
+        try:
+            if cfg.LASER_EXTRACTOR_TYPE == 'simple':
+                self.laser_extractor = SimpleLaserExtractor(hsv_lower=cfg.SIMPLE_LASER_HSV_LOWER, hsv_upper=cfg.SIMPLE_LASER_HSV_UPPER,
+                                                            brightness_threshold=cfg.SIMPLE_LASER_BRIGHTNESS_THRESHOLD,
+                                                            min_area=cfg.SIMPLE_LASER_MIN_AREA, device=self.device, verbose=self.verbose)
+            else:
+                self.laser_extractor = FastStegerExtractor(sigma=cfg.STEGER_SIGMA, brightness_threshold=cfg.STEGER_BRIGHTNESS_THRESHOLD,
+                                                           use_lut=cfg.STEGER_USE_LUT, device=self.device, verbose=self.verbose)
+        except Exception as e:
+            self._log(f"laser extractor initialisation error: {e}")
+            return False
+        try:
+            intr = self.camera.get_camera_intrinsics()
+            if intr is None:
+                self._log("no camera intrinsics")
+                return False
+            K = np.array([[intr['fx'], 0, intr['cx']], [0, intr['fy'], intr['cy']], [0, 0, 1]], dtype=np.float64)
+            self.reconstructor = Reconstructor(camera_intrinsic=K, laser_plane=cfg.LASER_PLANE_COEFFICIENTS,
+                                               use_refraction_correction=cfg.USE_REFRACTION_CORRECTION, device=self.device)
+        except Exception as e:
+            self._log(f"reconstructor initialisation error: {e}")
+            return False
+        try:
+            self.point_cloud_processor = PointCloudProcessor(device=self.device)
+        except Exception as e:
+            self._log(f"point cloud processor initialisation error: {e}")
+            return False
+        return True
+
+    def process_frame(self):
+        """(color_image, depth_image, laser_points) of the next frame, or (None, None, None); the frame's valid 3-D
+        points are appended to ``point_cloud`` (main.py:164-189)."""
+        left, depth = self.camera.get_frames_device()
+        if left is None:
+            return None, None, None
+        steger_on_device = isinstance(self.laser_extractor, FastStegerExtractor) and left.dim() == 4
+        if steger_on_device:
+            h, w = left.shape[1:3]
+            xy, counts = self.laser_extractor.extract_device(left, w * h)
+            n = int(counts[0].item())
+            laser_points = _as_tuples(xy[0, :n].cpu().numpy())
+            points_3d = np.empty((0, 3))
+            if n > 0:
+                xyz, keep = self.reconstructor.reconstruct_from_depth_device(xy, counts, depth)
+                points_3d = xyz[0, :n][keep[0, :n] != 0].cpu().numpy()
+        color_image = left[0].cpu().numpy()
+        depth_image = depth[0].cpu().numpy()
+        if not steger_on_device:
+            if isinstance(self.laser_extractor, SimpleLaserExtractor) and left.dim() == 4:
+                laser_points = self.laser_extractor.extract_device(left[0])
+            else:
+                laser_points = self.laser_extractor.extract_centerline(color_image)
+            points_3d = self.reconstructor.reconstruct_from_depth(laser_points, depth_image) if len(laser_points) > 0 else []
+        if len(points_3d) > 0:
+            points_3d = points_3d[~np.isnan(points_3d).any(axis=1)]
+            self.point_cloud.extend(points_3d.tolist())
+        self.frame_count += 1
+        return color_image, depth_image, laser_points
+
+    def save_point_cloud(self, filename=None) -> bool:
+        """Voxel downsampling, outlier removal and the PLY / PCD writer with the Config's knobs (main.py:191-233)."""
+        cfg = self.config
+        if len(self.point_cloud) < cfg.MIN_POINT_CLOUD_SIZE:
+            self._log(f"point cloud too small ({len(self.point_cloud)} < {cfg.MIN_POINT_CLOUD_SIZE}): not saved")
+            return False
+        os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+        if filename is None:
+            filename = f"point_cloud_{time.strftime('%Y%m%d_%H%M%S')}.{cfg.SAVE_FORMAT}"
+        path = os.path.join(cfg.OUTPUT_DIR, filename)
+        points = np.array(self.point_cloud, dtype=np.float32)
+        points = self.point_cloud_processor.voxel_downsample(points, voxel_size=cfg.VOXEL_SIZE)
+        points = self.point_cloud_processor.statistical_outlier_removal(points, nb_neighbors=cfg.OUTLIER_REMOVAL_NEIGHBORS,
+                                                                        std_ratio=cfg.OUTLIER_REMOVAL_STD_RATIO)
+        if cfg.SAVE_FORMAT == 'ply':
+            self.point_cloud_processor.save_ply(points, path)
+        else:
+            self.point_cloud_processor.save_pcd(points, path)
+        self._log(f"point cloud saved: {path} ({len(points)} points)")
+        return True
+
+    def run(self, max_frames=None, duration=None) -> int:
+        """The frame loop of run_realtime (main.py:252-265) without its display: processes frames until the source
+        runs dry, ``max_frames`` are done or ``duration`` seconds have passed; returns the number of frames."""
+        self.start_time = time.time()
+        done = 0
+        while max_frames is None or done < max_frames:
+            if duration and time.time() - self.start_time > duration:
+                break
+            color_image, _, _ = self.process_frame()
+            if color_image is None:
+                break
+            done += 1
+        return done

@@ -1,4 +1,4 @@
-"""A stand-in for the `cv2` module, for the golden-vector generators only (make_laser_golden.py, make_depth_golden.py).
+"""A stand-in for the `cv2` module, for the golden-vector generators only (the make_*_golden.py scripts beside it).
 
 OpenCV is not installed in the build container.  The reference's modules call it for their image operators; to run
 the reference's OWN Python around those calls, this module object answers the same names with the CPU oracle's
@@ -194,4 +194,52 @@ def add_stereo_names(cv2):
 
     cv2.reprojectImageTo3D = reprojectImageTo3D
     cv2.remap = remap
+    return cv2
+
+
+def add_capture_names(cv2, frames, stereo_rectify):
+    """The names SingleUSBStereoCameraManager.initialize / _load_calibration use (reference :93-113, 176-206):
+    VideoCapture (hands out `frames` in turn, round and round, and counts the reads in VideoCapture.reads),
+    stereoRectify (`stereo_rectify`: a host-side function supplied by the caller -- its results are INPUT data of the
+    vectors, stored with them), initUndistortRectifyMap (the oracle's restatement)."""
+    cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT, cv2.CAP_PROP_FPS = 3, 4, 5
+    cv2.CALIB_ZERO_DISPARITY = 1024
+    cv2.CV_32FC1 = 5
+
+    class VideoCapture:
+        reads = 0
+        rectified = None      # what stereoRectify returned last, for the generator to store
+
+        def __init__(self, camera_id):
+            self.camera_id, self.props = camera_id, {}
+
+        def isOpened(self):
+            return True
+
+        def set(self, prop, value):
+            self.props[prop] = value
+            return True
+
+        def get(self, prop):
+            return self.props.get(prop, 0)
+
+        def read(self):
+            frame = frames[VideoCapture.reads % len(frames)]
+            VideoCapture.reads += 1
+            return True, frame.copy()
+
+        def release(self):
+            pass
+
+    def stereoRectify(K1, D1, K2, D2, size, R, T, flags=0, alpha=-1):
+        assert flags == cv2.CALIB_ZERO_DISPARITY
+        out = stereo_rectify(K1, D1, K2, D2, size, R, T, alpha=alpha)
+        VideoCapture.rectified = out
+        return out
+
+    def initUndistortRectifyMap(K, D, R, P, size, m1type):
+        assert m1type == cv2.CV_32FC1
+        return O.init_undistort_rectify_map(K, D, R, P, size)
+
+    cv2.VideoCapture, cv2.stereoRectify, cv2.initUndistortRectifyMap = VideoCapture, stereoRectify, initUndistortRectifyMap
     return cv2

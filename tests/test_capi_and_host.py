@@ -142,6 +142,37 @@ def test_camera_manager_surface_and_knobs():
     assert cam.get_camera_intrinsics()["fx"] == 350.0 and cam.get_camera_intrinsics()["baseline"] == 0.06
 
 
+def test_reconstruction_system_surface():
+    """The attributes and return conventions of the reference's LaserReconstructionSystem (main.py:40-49, 164-169, 193-195)."""
+    from laser_3d_reconstruction_amd import Config, LaserReconstructionSystem
+
+    class Source:
+        def __init__(self, ok):
+            self.ok, self.reads = ok, 0
+
+        def isOpened(self):
+            return True
+
+        def read(self):
+            self.reads += 1
+            return (True, np.zeros((240, 640, 3), np.uint8)) if self.ok else (False, None)
+
+        def release(self):
+            pass
+
+    s = LaserReconstructionSystem()
+    assert isinstance(s.config, Config) and s.point_cloud == [] and s.frame_count == 0 and s.show_depth is True
+    for attr in ("camera", "laser_extractor", "reconstructor", "point_cloud_processor", "start_time"):
+        assert getattr(s, attr) is None
+    assert s.initialize() is False                       # no frame source: the camera cannot be opened
+    assert s.camera is not None and (s.camera.camera_id, s.camera.width, s.camera.height) == (1, 640, 240)
+    src = Source(ok=False)
+    s = LaserReconstructionSystem(frame_source=src)
+    assert s.initialize(camera_id=0, width=1280, height=360) is False and src.reads == 1   # the test read failed
+    assert (s.camera.camera_id, s.camera.single_width) == (0, 640) and s.laser_extractor is None
+    assert s.save_point_cloud() is False                 # fewer points than MIN_POINT_CLOUD_SIZE
+
+
 def test_camera_manager_loads_reference_style_calibration(tmp_path):
     import json
     from laser_3d_reconstruction_amd import SingleUSBStereoCameraManager
