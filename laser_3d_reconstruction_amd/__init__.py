@@ -5,7 +5,8 @@ modules the reference keeps at its top level are mirrored as submodules:
 ``improved_steger`` (ImprovedStegerExtractor, HybridLaserExtractor),
 ``improved_reconstruction`` (ImprovedLaserReconstructor, fix_roi_alignment),
 ``camera.rectify`` (stereo_rectify, Rectifier); ``system.LaserReconstructionSystem`` is the frame loop of the
-reference's main.py (initialize / process_frame / save_point_cloud).
+reference's main.py (initialize / process_frame / save_point_cloud), ``system.ImprovedLaserSystem`` the one of
+test_improved_laser.py, ``point_cloud_collector`` its collector classes.
 """
 __version__ = "0.1.0"
 

@@ -53,7 +53,10 @@ class SingleUSBStereoCameraManager:
         self.R = None
         self.T = None
         self.R1 = self.R2 = self.P1 = self.P2 = self.Q = None
+        # as in the reference, where stereoRectify's valid rectangles go to local names (:176) and these two stay None
+        # (callers test them: test_improved_laser.py:137); the rectangles themselves are kept in valid_roi_left / _right
         self.roi_left = self.roi_right = None
+        self.valid_roi_left = self.valid_roi_right = None
         self.rectifier_left = self.rectifier_right = None
         self.stereo_matcher = None
         self.right_matcher = None
@@ -120,7 +123,7 @@ class SingleUSBStereoCameraManager:
                     setattr(self, key, np.array(calib[key], dtype=np.float64))
             else:
                 image_size = (self.single_width, self.single_height)
-                self.R1, self.R2, self.P1, self.P2, self.Q, self.roi_left, self.roi_right = rectify.stereo_rectify(
+                self.R1, self.R2, self.P1, self.P2, self.Q, self.valid_roi_left, self.valid_roi_right = rectify.stereo_rectify(
                     self.camera_matrix_left, self.dist_coeffs_left, self.camera_matrix_right, self.dist_coeffs_right,
                     image_size, self.R, self.T, flags=rectify.CALIB_ZERO_DISPARITY, alpha=0)
             self.rectifier_left = self.rectifier_right = None  # built on the device at first use

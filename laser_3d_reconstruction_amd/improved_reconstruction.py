@@ -56,6 +56,27 @@ class ImprovedLaserReconstructor:
         # window_size // 2 defines the window: an even size covers the next odd one, as in the reference's slicing
         return self._triangulate(laser_points, disparity_map, 2 * (int(window_size) // 2) + 1, min_disparity)
 
+    def triangulate_device(self, uv, disparity, window_size: int = 3, min_disparity: float = 1.0):
+        """Device-resident form of reconstruct_with_interpolation (window_size >= 1) and reconstruct_from_disparity
+        (window_size = 0): uv (n,2) float64 and disparity (H,W) float32 CUDA tensors -> (xyz (n,3) float32, keep (n,)
+        int32); row i is a point of the host method's result where keep is 1.  Runs on torch's current stream."""
+        import torch
+
+        assert uv.is_cuda and uv.dtype == torch.float64 and uv.is_contiguous() and uv.dim() == 2 and uv.shape[1] == 2
+        assert disparity.is_cuda and disparity.dtype == torch.float32 and disparity.is_contiguous() and disparity.dim() == 2
+        n = uv.shape[0]
+        h, w = disparity.shape
+        xyz = torch.empty((n, 3), dtype=torch.float32, device=uv.device)
+        keep = torch.empty((n,), dtype=torch.int32, device=uv.device)
+        if n:
+            ws = 2 * (int(window_size) // 2) + 1 if window_size else 0
+            N.check(N.lib.l3d_triangulate_disparity_device(C.c_void_p(uv.data_ptr()), n, C.c_void_p(disparity.data_ptr()), w, h,
+                                                           N.ptr(self._q), ws, C.c_double(float(min_disparity)),
+                                                           C.c_void_p(xyz.data_ptr()), C.c_void_p(keep.data_ptr()),
+                                                           C.c_void_p(torch.cuda.current_stream(uv.device).cuda_stream)),
+                    "l3d_triangulate_disparity_device")
+        return xyz, keep
+
     def create_laser_depth_map(self, laser_points: List[Tuple[float, float]], disparity_map: np.ndarray,
                                image_shape: Tuple[int, int]) -> np.ndarray:
         h, w = image_shape

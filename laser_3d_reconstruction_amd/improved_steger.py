@@ -87,6 +87,25 @@ class ImprovedStegerExtractor:
                 "l3d_steger_extract_improved")
         return xy[: n.value].copy()
 
+    def extract_device(self, image, per_row: bool = False):
+        """torch uint8 CUDA tensor (H,W,3) or (H,W) -> (xy (capacity,2) float32, count (1,) int32) on the device, on
+        torch's current stream; the first count rows of xy are the points of extract_points."""
+        import torch
+
+        assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous()
+        assert image.dim() == 2 or (image.dim() == 3 and image.shape[2] == 3)
+        ch = 3 if image.dim() == 3 else 1
+        h, w = image.shape[:2]
+        hd = self._handle.get(w, h, (self.sigma, self.brightness_threshold, self.response_threshold))
+        cap = h if per_row else w * h
+        xy = torch.empty((cap, 2), dtype=torch.float32, device=image.device)
+        count = torch.empty((1,), dtype=torch.int32, device=image.device)
+        N.check(N.lib.l3d_steger_extract_improved_device(hd, C.c_void_p(image.data_ptr()), ch, w, h, 1, int(per_row),
+                                                         C.c_void_p(xy.data_ptr()), cap, C.c_void_p(count.data_ptr()),
+                                                         C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                "l3d_steger_extract_improved_device")
+        return xy, count
+
     def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
         """Every accepted bright pixel, raster order (improved_steger.py:39-126)."""
         return [(float(x), float(y)) for x, y in self.extract_points(image, per_row=False)]
@@ -147,6 +166,25 @@ class HybridLaserExtractor:
                                          N.ptr(mask) if want_mask else None), "l3d_hybrid_extract")
         pts = xy[: n.value].copy()
         return (pts, mask) if want_mask else pts
+
+    def extract_device(self, image):
+        """torch uint8 CUDA tensor (H,W,3) -> (xy (H,2) float32, count (1,) int32) on the device, on torch's current
+        stream; the first count rows of xy are the points of extract_points."""
+        import torch
+
+        assert image.is_cuda and image.dtype == torch.uint8 and image.is_contiguous() and image.dim() == 3 and image.shape[2] == 3
+        h, w = image.shape[:2]
+        st = self._handle.get(w, h, (self.sigma, self.brightness_threshold, 0.5))
+        mk = self._mask_maker(w, h)
+        lo = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_lower).reshape(3)])
+        hi = (C.c_int * 3)(*[int(v) for v in np.asarray(self.hsv_upper).reshape(3)])
+        xy = torch.empty((h, 2), dtype=torch.float32, device=image.device)
+        count = torch.empty((1,), dtype=torch.int32, device=image.device)
+        N.check(N.lib.l3d_hybrid_extract_device(mk, st, C.c_void_p(image.data_ptr()), w, h, lo, hi, int(self.brightness_threshold),
+                                                C.c_void_p(xy.data_ptr()), h, C.c_void_p(count.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)),
+                "l3d_hybrid_extract_device")
+        return xy, count
 
     def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
         return [(float(x), float(y)) for x, y in self.extract_points(image)]

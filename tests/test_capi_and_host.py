@@ -173,6 +173,48 @@ def test_reconstruction_system_surface():
     assert s.save_point_cloud() is False                 # fewer points than MIN_POINT_CLOUD_SIZE
 
 
+def test_point_cloud_collector_bookkeeping(tmp_path):
+    """Counters, default colours, statistics keys, automatic saves and the file pair of the reference's collector
+    (point_cloud_collector.py:41-67, 185-212, 278-306); clouds this small skip the downsampling and outlier steps."""
+    import json
+    from laser_3d_reconstruction_amd.point_cloud_collector import PointCloudCollector, RealTimePointCloudCollector
+
+    c = PointCloudCollector(output_dir=str(tmp_path / "a"))
+    assert c.get_statistics() == {'frame_count': 0, 'total_points': 0, 'avg_points_per_frame': 0}
+    assert c.save() == "" and c.export_numpy() == ""
+    c.add_points(np.zeros((0, 3)))
+    assert c.frame_count == 0
+    p1 = np.arange(12, dtype=np.float64).reshape(4, 3)
+    c.add_points(p1)
+    c.add_points(p1[:2] + 100, np.full((2, 3), 0.5))
+    assert (c.frame_count, c.total_points) == (2, 6)
+    pts, cols = c.get_point_cloud()
+    assert pts.shape == (6, 3) and cols[:4].tolist() == [[0, 1, 0]] * 4 and cols[4:].tolist() == [[0.5] * 3] * 2
+    st = c.get_statistics()
+    assert st['unique_points'] == 6 and st['avg_points_per_frame'] == 3 and st['bounds_min'] == [0, 1, 2] and st['bounds_max'] == [103, 104, 105]
+    path = c.save(filename="cloud")
+    header, body = open(path, "rb").read().split(b"end_header\n", 1)
+    assert path.endswith("cloud.ply") and b"element vertex 6" in header and len(body) == 6 * 27
+    rec = np.frombuffer(body, np.dtype([("xyz", "<f8", 3), ("rgb", "u1", 3)]))
+    assert np.array_equal(rec["xyz"], pts) and rec["rgb"][0].tolist() == [0, 255, 0] and rec["rgb"][5].tolist() == [128, 128, 128]
+    meta = json.load(open(tmp_path / "a" / "cloud_metadata.json"))
+    assert meta["total_points"] == 6 and meta["frame_count"] == 2 and meta["final_points"] == 6 and meta["voxel_size"] == 0.002
+    assert c.save(format="obj") == ""
+    assert c.export_numpy("n").endswith("n_points.npy") and np.array_equal(np.load(tmp_path / "a" / "n_colors.npy"), cols)
+    c.clear()
+    assert (c.frame_count, c.total_points, c.points, c.colors) == (0, 0, [], [])
+
+    r = RealTimePointCloudCollector(output_dir=str(tmp_path / "b"), auto_save_interval=2, max_points=10)
+    r.add_points(p1)
+    assert (r.frames_since_save, r.save_count) == (1, 0)
+    r.add_points(np.zeros((0, 3)))                       # an empty frame still counts towards the interval
+    assert (r.frames_since_save, r.save_count, r.frame_count) == (0, 1, 1)
+    r.add_points(p1)
+    r.add_points(p1)                                     # interval reached again, then 12 points >= max_points: saved and emptied
+    assert r.save_count == 3 and r.total_points == 0 and r.points == []
+    assert len([f for f in os.listdir(tmp_path / "b") if f.endswith(".ply")]) == 3
+
+
 def test_camera_manager_loads_reference_style_calibration(tmp_path):
     import json
     from laser_3d_reconstruction_amd import SingleUSBStereoCameraManager
@@ -193,7 +235,8 @@ def test_camera_manager_loads_reference_style_calibration(tmp_path):
     assert abs(k["baseline"] - np.linalg.norm(calib["T"])) < 1e-12
     assert cam.Q.shape == (4, 4) and cam.Q[2, 3] == cam.P1[0, 0] and cam.Q[0, 3] == -cam.P1[0, 2]
     assert abs(cam.P2[0, 3] / cam.P2[0, 0] + np.linalg.norm(calib["T"])) < 1e-6     # Tx * f, rotated baseline
-    assert cam.roi_left[2] > 300 and cam.roi_left[3] > 220
+    assert cam.valid_roi_left[2] > 300 and cam.valid_roi_left[3] > 220
+    assert cam.roi_left is None and cam.roi_right is None      # the reference never assigns them
 
 
 def _random_rig(rng):
