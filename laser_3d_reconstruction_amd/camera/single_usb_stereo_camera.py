@@ -62,6 +62,7 @@ class SingleUSBStereoCameraManager:
         self.right_matcher = None
         self.wls_filter = None
         self.use_wls = True
+        self._side_stream = None       # the right matcher's stream (see _depth_on_device)
 
         if split_mode == 'horizontal':
             self.single_width = width // 2
@@ -222,10 +223,23 @@ class SingleUSBStereoCameraManager:
         """(B,H,W) uint8 gray tensors on the GPU -> float32 depth tensor; nothing leaves the device in between."""
         if self.stereo_matcher is None:
             self._initialize_stereo_matcher_optimized()
-        d = self.stereo_matcher.compute_device(gl, gr)
         if self.use_wls and self.wls_filter is not None:
-            dr = self.right_matcher.compute_device(gr, gl)
+            # The two matchers are independent, and one frame leaves most of the chip idle: the right matcher runs on
+            # a stream of its own beside the left one, and the filter waits for both.
+            import torch
+
+            cur = torch.cuda.current_stream(gl.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=gl.device)
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                dr = self.right_matcher.compute_device(gr, gl)
+            d = self.stereo_matcher.compute_device(gl, gr)
+            cur.wait_stream(self._side_stream)
+            dr.record_stream(cur)
             d = self.wls_filter.filter_device(d, gl, dr)
+        else:
+            d = self.stereo_matcher.compute_device(gl, gr)
         return ops.depth_from_disparity16_device(d, self.Q)
 
     def _upload(self, img: np.ndarray):
@@ -244,10 +258,12 @@ class SingleUSBStereoCameraManager:
         gr = ops.bgr2gray_device(R) if R.dim() == 4 else R
         return self._depth_on_device(gl, gr)[0].cpu().numpy()
 
-    def get_frames_device(self):
+    def get_frames_device(self, rectified_event=None):
         """The next frame as CUDA tensors: (rectified left image (1,H,W,3) or (1,H,W) uint8, depth map (1,H,W) float32),
         or (None, None) when no frame can be read.  What get_frames downloads; a caller that goes on working on the
-        device (laser extractor, back-projection) starts from here."""
+        device (laser extractor, back-projection) starts from here.  `rectified_event` (a torch.cuda.Event) is recorded
+        on the current stream once the rectified left image is complete, ahead of the matchers: work that needs only
+        that image can wait for it on another stream and run beside them."""
         if self.cap is None or not self.cap.isOpened():
             return None, None
         ret, frame = self.cap.read()
@@ -261,6 +277,8 @@ class SingleUSBStereoCameraManager:
             if left_rectified.shape != right_rectified.shape or left_rectified.dtype != np.uint8 or right_rectified.dtype != np.uint8:
                 raise ValueError("get_frames expects the two eyes as uint8 images of one shape")
             L, R = self._upload(left_rectified)[None], self._upload(right_rectified)[None]
+            if rectified_event is not None:
+                rectified_event.record()
             gl = ops.bgr2gray_device(L) if L.dim() == 4 else L
             gr = ops.bgr2gray_device(R) if R.dim() == 4 else R
             return L, self._depth_on_device(gl, gr)
@@ -273,6 +291,8 @@ class SingleUSBStereoCameraManager:
         right_off = w * ch if self.split_mode == 'horizontal' else h * fw * ch
         view = dict(row_stride=fw * ch, img_stride=fh * fw * ch, src_size=(w, h))
         left_rect, gl = self.rectifier_left.remap_device(F, want_bgr=True, want_gray=True, **view)
+        if rectified_event is not None:
+            rectified_event.record()
         _, gr = self.rectifier_right.remap_device(F, want_bgr=False, want_gray=True, offset_bytes=right_off, **view)
         return left_rect, self._depth_on_device(gl, gr)
 

@@ -86,16 +86,39 @@ __global__ void __launch_bounds__(256) k_morph3(const uint8_t *__restrict__ src,
     dst[(size_t)y * W + x] = (uint8_t)acc;
 }
 
-__global__ void __launch_bounds__(256) k_lab_init(int n1, int *lab)
+// Labelling, step 1: a pixel's label starts as the index of the first pixel of its row run -- the pixels next to each
+// other in a row that the labelling joins anyway (background pixels, blocked[i] == 0, and with fg8 the blocked ones;
+// without fg8 a blocked pixel is a run of its own).  One wave per image row finds the run starts of 64 pixels with one
+// ballot.  The unions along rows, which were nearly all of them (the background of a laser frame is one component of
+// a few hundred thousand pixels, every union contending for the same root: 0.5 ms per 640x360 frame), are then not needed.
+// Node n = W * H, "outside the image", is initialised by the first row's wave.
+__global__ void __launch_bounds__(64) k_lab_runs(const uint8_t *__restrict__ blocked, int W, int H, int fg8, int *__restrict__ lab)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n1) lab[i] = i;
+    const int y = blockIdx.x, lane = threadIdx.x;
+    int carry_cls = -1, carry_start = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool valid = x < W;
+        const int cls = valid ? (blocked[(size_t)y * W + x] != 0 ? 1 : 0) : 2;
+        int prev = __shfl_up(cls, 1);
+        if (lane == 0) prev = carry_cls;
+        const bool joins_left = cls == prev && (cls == 0 || fg8);
+        const unsigned long long starts = __ballot(valid && !joins_left);
+        const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+        const int sx = below ? x0 + 63 - __clzll(below) : carry_start;
+        if (valid) lab[(size_t)y * W + x] = y * W + sx;
+        carry_cls = __shfl(cls, 63);
+        carry_start = __shfl(sx, 63);
+    }
+    if (y == 0 && lane == 0) lab[(size_t)W * H] = W * H;
 }
 
-// Nodes: every pixel plus node n = "outside the image".  Pixels with blocked[i] != 0 are joined
+// Labelling, step 2.  Nodes: every pixel plus node n = "outside the image".  Pixels with blocked[i] != 0 are joined
 // with 8-connectivity among themselves when fg8 is set (foreground components) or left isolated
 // when it is not; pixels with blocked[i] == 0 are joined with 4-connectivity among themselves and
-// with the outside node along the image border.
+// with the outside node along the image border.  The row runs are joined already (k_lab_runs): what is left are the
+// links between adjacent rows.  For the background one union per pair of overlapping runs is enough: at the first
+// column of the overlap one of the two runs starts.
 __global__ void __launch_bounds__(256) k_lab_merge(const uint8_t *__restrict__ blocked, int W, int H, int fg8, int *lab)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -104,26 +127,49 @@ __global__ void __launch_bounds__(256) k_lab_merge(const uint8_t *__restrict__ b
     const bool f = blocked[i] != 0;
     if (f) {
         if (!fg8) return;
-        if (x + 1 < W && blocked[i + 1]) s_uf_union(lab, i, i + 1);
         if (y + 1 < H) {
             if (blocked[i + W]) s_uf_union(lab, i, i + W);
             if (x + 1 < W && blocked[i + W + 1]) s_uf_union(lab, i, i + W + 1);
             if (x > 0 && blocked[i + W - 1]) s_uf_union(lab, i, i + W - 1);
         }
     } else {
-        if (x + 1 < W && !blocked[i + 1]) s_uf_union(lab, i, i + 1);
-        if (y + 1 < H && !blocked[i + W]) s_uf_union(lab, i, i + W);
-        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) s_uf_union(lab, i, n);
+        // (in the first column both pixels of a vertical pair are joined with the outside node anyway; leaving that pair out
+        // keeps the big outside component a star around node n instead of a chain down the image's left edge)
+        const bool starts = x == 0 || blocked[i - 1];
+        if (x > 0 && y + 1 < H && !blocked[i + W] && (starts || blocked[i + W - 1])) s_uf_union(lab, i, i + W);
+        if (x == 0 || x == W - 1 || ((y == 0 || y == H - 1) && starts)) s_uf_union(lab, i, n);
     }
 }
 
+// Labelling, step 3: every node's label becomes the root of its component.  First the run starts and the outside node
+// walk to their roots (they hold the long chains, one link per image row at worst; a label only ever moves towards the
+// root, so a walk that meets a label another thread has just shortened still ends at the root) ...
+__global__ void __launch_bounds__(256) k_lab_flatten_heads(const uint8_t *__restrict__ blocked, int W, int H, int fg8, int *lab)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int i = y * W + x;
+    if (x > 0) {
+        const bool f = blocked[i] != 0, fl = blocked[i - 1] != 0;
+        if (f == fl && (!f || fg8)) return;      // inside a run
+    }
+    int r = i, p;
+    while ((p = s_uf_load(lab, r)) != r) r = p;
+    __hip_atomic_store(lab + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == 0) {                                // the outside node
+        r = W * H;
+        while ((p = s_uf_load(lab, r)) != r) r = p;
+        __hip_atomic_store(lab + W * H, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ... then every other pixel takes the root from its run start.
 __global__ void __launch_bounds__(256) k_lab_flatten(int n1, int *lab)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n1) return;
-    int r = i, p;
-    while ((p = lab[r]) != r) r = p;
-    lab[i] = r;
+    const int h = s_uf_load(lab, i);
+    const int r = s_uf_load(lab, h);
+    if (r != h) __hip_atomic_store(lab + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one thread per 2x2 cell with top-left corner (cx, cy), cx in [-1, W-1], cy in [-1, H-1]
@@ -330,16 +376,18 @@ static int simple_run(l3d_simple *h, const uint8_t *d_bgr, int W, int H, const i
     hipLaunchKernelGGL(k_morph3, g2, b, 0, s, h->m1, W, H, 1, h->m0);
     if (masks) L3D_HIP_CHECK(hipMemcpyAsync(masks + n, h->m0, n, hipMemcpyDeviceToHost, s));
     // components of the mask and of its background
-    hipLaunchKernelGGL(k_lab_init, g11, b, 0, s, n1, h->lab);
+    hipLaunchKernelGGL(k_lab_runs, dim3(H), dim3(64), 0, s, h->m0, W, H, 1, h->lab);
     hipLaunchKernelGGL(k_lab_merge, g2, b, 0, s, h->m0, W, H, 1, h->lab);
+    hipLaunchKernelGGL(k_lab_flatten_heads, g2, b, 0, s, h->m0, W, H, 1, h->lab);
     hipLaunchKernelGGL(k_lab_flatten, g11, b, 0, s, n1, h->lab);
     L3D_HIP_CHECK(hipMemsetAsync(h->area2, 0, (size_t)n1 * sizeof(long long), s));
     L3D_HIP_CHECK(hipMemsetAsync(h->touch, 0, (size_t)n1 * sizeof(int), s));
     hipLaunchKernelGGL(k_contour_area, dim3(cdiv(W + 1, 256), H + 1), b, 0, s, h->m0, h->lab, W, H, h->area2, h->touch);
     hipLaunchKernelGGL(k_keep, g1, b, 0, s, h->m0, h->lab, n, h->area2, h->touch, min_area, h->kept);
     // filled contours: whatever a 4-connected flood from outside cannot reach around the kept components
-    hipLaunchKernelGGL(k_lab_init, g11, b, 0, s, n1, h->lab2);
+    hipLaunchKernelGGL(k_lab_runs, dim3(H), dim3(64), 0, s, h->kept, W, H, 0, h->lab2);
     hipLaunchKernelGGL(k_lab_merge, g2, b, 0, s, h->kept, W, H, 0, h->lab2);
+    hipLaunchKernelGGL(k_lab_flatten_heads, g2, b, 0, s, h->kept, W, H, 0, h->lab2);
     hipLaunchKernelGGL(k_lab_flatten, g11, b, 0, s, n1, h->lab2);
     hipLaunchKernelGGL(k_final_mask, g1, b, 0, s, h->kept, h->lab2, n, h->fin);
     if (masks) L3D_HIP_CHECK(hipMemcpyAsync(masks + 2 * (size_t)n, h->fin, n, hipMemcpyDeviceToHost, s));

@@ -47,6 +47,7 @@ class LaserReconstructionSystem:
         self.frame_count = 0
         self.start_time = None
         self.show_depth = True
+        self._side_stream = None       # the laser extractor's stream (see process_frame)
 
     def _log(self, msg):
         if self.verbose:
@@ -99,11 +100,16 @@ class LaserReconstructionSystem:
     def process_frame(self):
         """(color_image, depth_image, laser_points) of the next frame, or (None, None, None); the frame's valid 3-D
         points are appended to ``point_cloud`` (main.py:164-189)."""
-        left, depth = self.camera.get_frames_device()
+        import torch
+
+        rectified = torch.cuda.Event()
+        left, depth = self.camera.get_frames_device(rectified_event=rectified)
         if left is None:
             return None, None, None
         steger_on_device = isinstance(self.laser_extractor, FastStegerExtractor) and left.dim() == 4
+        simple_on_device = isinstance(self.laser_extractor, SimpleLaserExtractor) and left.dim() == 4
         if steger_on_device:
+            # (three short kernels behind the depth map's: nothing to gain from a stream of their own)
             h, w = left.shape[1:3]
             xy, counts = self.laser_extractor.extract_device(left, w * h)
             n = int(counts[0].item())
@@ -112,12 +118,21 @@ class LaserReconstructionSystem:
             if n > 0:
                 xyz, keep = self.reconstructor.reconstruct_from_depth_device(xy, counts, depth)
                 points_3d = xyz[0, :n][keep[0, :n] != 0].cpu().numpy()
+        elif simple_on_device:
+            # The Simple extractor needs only the rectified left image and ends with a host synchronisation: it waits for
+            # that image on a stream of its own and runs beside the matchers and the disparity filter, which leave most
+            # of the chip idle on a single frame.
+            cur = torch.cuda.current_stream(left.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=left.device)
+            self._side_stream.wait_event(rectified)
+            with torch.cuda.stream(self._side_stream):
+                laser_points = self.laser_extractor.extract_device(left[0])
+            cur.wait_stream(self._side_stream)
         color_image = left[0].cpu().numpy()
         depth_image = depth[0].cpu().numpy()
         if not steger_on_device:
-            if isinstance(self.laser_extractor, SimpleLaserExtractor) and left.dim() == 4:
-                laser_points = self.laser_extractor.extract_device(left[0])
-            else:
+            if not simple_on_device:
                 laser_points = self.laser_extractor.extract_centerline(color_image)
             points_3d = self.reconstructor.reconstruct_from_depth(laser_points, depth_image) if len(laser_points) > 0 else []
         if len(points_3d) > 0:
