@@ -1414,6 +1414,13 @@ extern "C" int l3d_sgbm_create(const l3d_sgbm_params *p, int width, int height, 
         h->g.LPPh = 16;
         h->g.NPh = h->g.Dp / 32;
     }
+    // The same holds for the vertical kernel, whose blocks walk down their stripe one row after the other: with 16 lanes
+    // per pixel a row is half as many instructions per wave (one frame through the reference's frame loop at 64 / 5
+    // and at 96 / 7: +6 to +9 % frames per second).
+    if (max_batch <= 4 && h->g.Dp == h->g.D && h->g.D % 32 == 0 && h->g.LPPv == 8 && !std::getenv("L3D_SGBM_LPPV")) {
+        h->g.LPPv = 16;
+        h->g.NPv = h->g.Dp / 32;
+    }
     const SgbmGeom &g = h->g;
     if (g.W1 > 0 && g.stripe_overlap > g.stripe_sz) {
         delete h;
