@@ -330,6 +330,12 @@ int l3d_reconstruct_plane(const double *uv, int n, const double *Kinv9, const do
 int l3d_reconstruct_from_depth_device(const float *d_xy, const int *d_counts, int capacity, int batch,
                                       const float *d_depth, int width, int height, const double *K9, double *d_xyz,
                                       int *d_keep, void *stream);
+/* Reconstructor.reconstruct_from_depth (core/reconstruction.py:145-182) for one frame whose depth map is still in HBM
+ * and whose laser pixels are doubles (the row centroids of SimpleLaserExtractor, core/laser_extractor.py:88-98, are
+ * float64): d_uv n (u,v) doubles, d_depth [height][width] float32, d_xyz [n][3] doubles, d_keep [n] = 1 where the
+ * reference appends the point.  No compaction. */
+int l3d_reconstruct_from_depth_uv64_device(const double *d_uv, int n, const float *d_depth, int width, int height,
+                                           const double *K9, double *d_xyz, int *d_keep, void *stream);
 /* d_xyz [batch][capacity][3] doubles: rows of NaN where the reference returns NaN and past a frame's count */
 int l3d_reconstruct_plane_device(const float *d_xy, const int *d_counts, int capacity, int batch,
                                  const double *Kinv9, const double *plane4, int refraction, double n_water,

@@ -131,6 +131,7 @@ def _load():
         "l3d_nn_distances": (i, [vp, i, vp, i]),
         "l3d_reconstruct_plane": (i, [vp, i, vp, vp, i, C.c_double, vp, i]),
         "l3d_reconstruct_from_depth_device": (i, [vp, vp, i, i, vp, i, i, vp, vp, vp, vp]),
+        "l3d_reconstruct_from_depth_uv64_device": (i, [vp, i, vp, i, i, vp, vp, vp, vp]),
         "l3d_reconstruct_plane_device": (i, [vp, vp, i, i, vp, vp, i, C.c_double, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -71,6 +71,26 @@ class Reconstructor:
                 "l3d_reconstruct_from_depth_device")
         return xyz, keep
 
+    def reconstruct_from_depth_uv64_device(self, uv, depth):
+        """uv (n,2) float64 and depth (H,W) float32 CUDA tensors -> (xyz (n,3) float64, keep (n,) int32): the form for
+        laser pixels that are doubles (SimpleLaserExtractor's row centroids) and a depth map that is still on the device."""
+        import ctypes as C
+        import torch
+        from .. import _native as N
+
+        assert uv.is_cuda and uv.dtype == torch.float64 and uv.is_contiguous() and uv.dim() == 2 and uv.shape[1] == 2
+        assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous() and depth.dim() == 2
+        n = uv.shape[0]
+        h, w = depth.shape
+        xyz = torch.empty((n, 3), dtype=torch.float64, device=uv.device)
+        keep = torch.empty((n,), dtype=torch.int32, device=uv.device)
+        k = np.ascontiguousarray(self.K, np.float64)
+        N.check(N.lib.l3d_reconstruct_from_depth_uv64_device(C.c_void_p(uv.data_ptr()), n, C.c_void_p(depth.data_ptr()), w, h, N.ptr(k),
+                                                             C.c_void_p(xyz.data_ptr()), C.c_void_p(keep.data_ptr()),
+                                                             C.c_void_p(torch.cuda.current_stream(uv.device).cuda_stream)),
+                "l3d_reconstruct_from_depth_uv64_device")
+        return xyz, keep
+
     def reconstruct_laser_line_device(self, xy, counts):
         """xy (B,cap,2) float32, counts (B,) int32 CUDA tensors -> xyz (B,cap,3) float64: reconstruct_point of every
         laser pixel (refraction as configured); rows of NaN where the reference drops the point."""

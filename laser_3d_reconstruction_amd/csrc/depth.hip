@@ -537,6 +537,18 @@ extern "C" int l3d_reconstruct_from_depth_device(const float *d_xy, const int *d
     return L3D_OK;
 }
 
+extern "C" int l3d_reconstruct_from_depth_uv64_device(const double *d_uv, int n, const float *d_depth, int width, int height,
+                                                      const double *K9, double *d_xyz, int *d_keep, void *stream)
+{
+    L3D_REQUIRE(n >= 0 && width > 0 && height > 0, "l3d_reconstruct_from_depth_uv64_device: bad size");
+    if (n == 0) return L3D_OK;
+    L3D_REQUIRE(d_uv && d_depth && K9 && d_xyz && d_keep, "l3d_reconstruct_from_depth_uv64_device: null argument");
+    hipLaunchKernelGGL(k_from_depth, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, d_uv, n, d_depth, width, height, K9[0], K9[4],
+                       K9[2], K9[5], d_xyz, d_keep);
+    L3D_HIP_CHECK(hipGetLastError());
+    return L3D_OK;
+}
+
 extern "C" int l3d_reconstruct_plane_device(const float *d_xy, const int *d_counts, int capacity, int batch, const double *Kinv9,
                                             const double *plane4, int refraction, double n_water, double *d_xyz, void *stream)
 {

@@ -129,11 +129,16 @@ class LaserReconstructionSystem:
             with torch.cuda.stream(self._side_stream):
                 laser_points = self.laser_extractor.extract_device(left[0])
             cur.wait_stream(self._side_stream)
+            points_3d = []
+            if len(laser_points) > 0:
+                # the centroids are doubles and go back up as they are; the depth map is read where it lies
+                uv = torch.tensor(np.asarray(laser_points, np.float64).reshape(-1, 2), dtype=torch.float64, device=left.device)
+                xyz, keep = self.reconstructor.reconstruct_from_depth_uv64_device(uv, depth[0])
+                points_3d = xyz[keep != 0].cpu().numpy()
         color_image = left[0].cpu().numpy()
         depth_image = depth[0].cpu().numpy()
-        if not steger_on_device:
-            if not simple_on_device:
-                laser_points = self.laser_extractor.extract_centerline(color_image)
+        if not steger_on_device and not simple_on_device:
+            laser_points = self.laser_extractor.extract_centerline(color_image)
             points_3d = self.reconstructor.reconstruct_from_depth(laser_points, depth_image) if len(laser_points) > 0 else []
         if len(points_3d) > 0:
             points_3d = points_3d[~np.isnan(points_3d).any(axis=1)]

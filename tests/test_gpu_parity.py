@@ -1049,6 +1049,17 @@ def test_device_resident_reconstruction_equals_host_entry_points_and_golden(gpu,
             assert np.array_equal(gp[:n][~np.isnan(gp[:n]).any(axis=1)], line)
             if n:
                 assert np.array_equal(gp[:n], O.reconstruct_plane(np.array(pts), K, r.laser_plane, refr, 1.33))
+    # laser pixels as doubles (the Simple extractor's centroids), depth map on the device: l3d_reconstruct_from_depth_uv64_device
+    r = Reconstructor(K, np.array([0.05, -0.02, 1.0, -0.5]))
+    uv64 = np.column_stack([rng.uniform(-3.0, W + 3.0, 500), rng.uniform(-3.0, H + 3.0, 500)])     # some outside the image
+    uv64[:50] = np.floor(uv64[:50]) + 0.5                                                        # round-half cases
+    xyz, keep = r.reconstruct_from_depth_uv64_device(torch.from_numpy(uv64).to(dev), d_depth[0])
+    got = xyz.cpu().numpy()[keep.cpu().numpy() == 1]
+    want = np.asarray(r.reconstruct_from_depth([tuple(p) for p in uv64], depth[0])).reshape(-1, 3)
+    assert 0 < len(want) < 500 and np.array_equal(got, want)
+    assert np.array_equal(want, O.reconstruct_from_depth(uv64, depth[0], K))
+    e_xyz, e_keep = r.reconstruct_from_depth_uv64_device(torch.zeros((0, 2), dtype=torch.float64, device=dev), d_depth[0])
+    assert e_xyz.shape == (0, 3) and e_keep.shape == (0,)
     # the golden plane cases through the device entry point: float32-representable pixel coordinates only
     case = golden["plane_cases"][0]
     uv = np.array(case["uv"], np.float64)
