@@ -246,6 +246,16 @@ int l3d_simple_extract(l3d_simple *h, const uint8_t *bgr, int width, int height,
 int l3d_simple_extract_device(l3d_simple *h, const uint8_t *d_bgr, int width, int height,
                               const int *hsv_lower, const int *hsv_upper, int brightness_threshold,
                               double min_area, double *xy, int *count, void *stream);
+/* The same for a stack of `batch` images [batch][height][width][3] in one sequence of launches (the reference calls
+ * extract_centerline once per frame, main.py:172; a caller with frames in hand batches them).  The handle comes from
+ * l3d_simple_create_batch (l3d_simple_create: max_batch = 1; 28 bytes of device memory per pixel of the stack).
+ * xy [batch][height][2] doubles, counts [batch]; image f's centres are the first counts[f] pairs of its slice. */
+int l3d_simple_create_batch(int max_width, int max_height, int max_batch, int device, l3d_simple **out);
+int l3d_simple_extract_batch(l3d_simple *h, const uint8_t *bgr, int width, int height, int batch, const int *hsv_lower,
+                             const int *hsv_upper, int brightness_threshold, double min_area, double *xy, int *counts);
+int l3d_simple_extract_batch_device(l3d_simple *h, const uint8_t *d_bgr, int width, int height, int batch,
+                                    const int *hsv_lower, const int *hsv_upper, int brightness_threshold,
+                                    double min_area, double *xy, int *counts, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Steger variants (improved_steger.py).  Points are float32 (x, y) pairs.

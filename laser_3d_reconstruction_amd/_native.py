@@ -111,6 +111,9 @@ def _load():
         "l3d_simple_destroy": (None, [vp]),
         "l3d_simple_extract": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
         "l3d_simple_extract_device": (i, [vp, vp, i, i, pi, pi, i, C.c_double, vp, pi, vp]),
+        "l3d_simple_create_batch": (i, [i, i, i, i, C.POINTER(vp)]),
+        "l3d_simple_extract_batch": (i, [vp, vp, i, i, i, pi, pi, i, C.c_double, vp, vp]),
+        "l3d_simple_extract_batch_device": (i, [vp, vp, i, i, i, pi, pi, i, C.c_double, vp, vp, vp]),
         "l3d_steger_create_improved": (i, [C.c_double, i, C.c_double, i, i, i, i, C.POINTER(vp)]),
         "l3d_steger_extract_improved": (i, [vp, vp, i, i, i, i, i, vp, i, vp]),
         "l3d_steger_extract_improved_device": (i, [vp, vp, i, i, i, i, i, vp, i, vp, vp]),

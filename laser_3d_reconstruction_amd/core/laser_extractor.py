@@ -30,7 +30,7 @@ class SimpleLaserExtractor:
         self.device = device
         self.verbose = verbose
         self._h = None
-        self._cap = (0, 0)
+        self._cap = (0, 0, 0)
         if verbose:
             print(f"SimpleLaserExtractor: HSV {self.hsv_lower} ~ {self.hsv_upper}, threshold {brightness_threshold}, "
                   f"min area {min_area}")
@@ -46,13 +46,14 @@ class SimpleLaserExtractor:
         except Exception:
             pass
 
-    def _handle(self, w, h):
-        mw, mh = self._cap
-        if self._h is None or w > mw or h > mh:
+    def _handle(self, w, h, b=1):
+        mw, mh, mb = self._cap
+        if self._h is None or w > mw or h > mh or b > mb:
             self._release()
-            self._cap = (max(w, mw), max(h, mh))
+            self._cap = (max(w, mw), max(h, mh), max(b, mb, 1))
             hd = C.c_void_p()
-            N.check(N.lib.l3d_simple_create(self._cap[0], self._cap[1], self.device, C.byref(hd)), "l3d_simple_create")
+            N.check(N.lib.l3d_simple_create_batch(self._cap[0], self._cap[1], self._cap[2], self.device, C.byref(hd)),
+                    "l3d_simple_create_batch")
             self._h = hd
         return self._h
 
@@ -80,6 +81,41 @@ class SimpleLaserExtractor:
 
     def extract_centerline(self, image: np.ndarray) -> List[Tuple[float, float]]:
         return _as_tuples(self.extract_points(image))
+
+    def extract_batch(self, images) -> List[List[Tuple[float, float]]]:
+        """A list (or (B,H,W,3) array) of BGR images of one shape -> one centre list per image, in one sequence of
+        launches; images of different shapes are processed one by one."""
+        if len(images) == 0:
+            return []
+        if len({np.asarray(im).shape for im in images}) != 1:
+            return [self.extract_centerline(im) for im in images]
+        img = np.ascontiguousarray(np.stack([np.asarray(im) for im in images]))
+        if img.dtype != np.uint8 or img.ndim != 4 or img.shape[3] != 3:
+            raise ValueError("SimpleLaserExtractor expects BGR uint8 images of shape (H, W, 3)")
+        b, h, w = img.shape[:3]
+        hd = self._handle(w, h, b)
+        lo, hi = self._range()
+        xy = np.empty((b, h, 2), np.float64)
+        counts = np.zeros(b, np.int32)
+        N.check(N.lib.l3d_simple_extract_batch(hd, N.ptr(img), w, h, b, lo, hi, int(self.brightness_threshold),
+                                               C.c_double(float(self.min_area)), N.ptr(xy), N.ptr(counts)), "l3d_simple_extract_batch")
+        return [_as_tuples(xy[f, : counts[f]]) for f in range(b)]
+
+    def extract_batch_device(self, images) -> List[List[Tuple[float, float]]]:
+        """torch uint8 CUDA tensor (B,H,W,3) -> one centre list per image; runs on torch's current stream."""
+        import torch
+
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous() and images.dim() == 4 and images.shape[3] == 3
+        b, h, w = images.shape[:3]
+        hd = self._handle(w, h, b)
+        lo, hi = self._range()
+        xy = np.empty((b, h, 2), np.float64)
+        counts = np.zeros(b, np.int32)
+        stream = C.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)
+        N.check(N.lib.l3d_simple_extract_batch_device(hd, C.c_void_p(images.data_ptr()), w, h, b, lo, hi, int(self.brightness_threshold),
+                                                      C.c_double(float(self.min_area)), N.ptr(xy), N.ptr(counts), stream),
+                "l3d_simple_extract_batch_device")
+        return [_as_tuples(xy[f, : counts[f]]) for f in range(b)]
 
     def extract_device(self, image):
         """torch uint8 CUDA tensor (H,W,3) -> list of (x, y); runs on torch's current stream."""

@@ -2,8 +2,9 @@
 against the CPU restatement (development aid, not part of the test suite): random image sizes (widths on both sides of
 the 64-pixel groups the row-run labelling works in), random blob fields with holes, islands inside holes, diagonally
 touching squares, components on the image border, thin lines and speckle, random area thresholds.  Compared: the three
-stage masks (combined, after morphology, filled contours) and the centre list, bit for bit.  One handle serves every
-case, so labels left over from a larger image would show in the next.
+stage masks (combined, after morphology, filled contours) and the centre list, bit for bit; every fifth case also as a
+stack of two to five images through the batch entry points.  One handle serves every case, so labels left over from a
+larger image would show in the next.
 usage: python scripts/gpu_stress_simple.py [cases] [seed]"""
 import os
 import sys
@@ -83,6 +84,11 @@ def main():
             import torch
             dev = ex.extract_device(torch.from_numpy(img).cuda())
             ok = np.array_equal(np.asarray(dev, np.float64).reshape(-1, 2), want)
+        if ok and case % 5 == 0:        # a stack of images of this size through the batch entry points, the handle reused
+            stack = [img] + [image(rng, W, H) for _ in range(int(rng.integers(1, 5)))]
+            wants = [O.simple_extract(f, LO, HI, THR, ex.min_area) for f in stack]
+            gots = ex.extract_batch(stack) if case % 10 else ex.extract_batch_device(__import__("torch").from_numpy(np.stack(stack)).cuda())
+            ok = all(np.array_equal(np.asarray(g, np.float64).reshape(-1, 2), w) for g, w in zip(gots, wants))
         rows += len(want)
         if not ok:
             bad += 1

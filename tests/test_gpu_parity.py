@@ -684,6 +684,39 @@ def test_simple_extractor_matches_oracle(gpu, O):
     assert np.array_equal(d.extract_points(lb), O.simple_extract(lb))
 
 
+def test_simple_extractor_batch_equals_single_calls(gpu, O):
+    """l3d_simple_extract_batch / _batch_device: a stack of frames in one sequence of launches gives, frame by frame, what
+    the single-image entry point gives (which the test above pins to the oracle)."""
+    import torch
+    from laser_3d_reconstruction_amd import Config, SimpleLaserExtractor
+    from tests.test_oracle import _blob_image
+
+    rng = np.random.default_rng(23)
+    args = (Config.SIMPLE_LASER_HSV_LOWER, Config.SIMPLE_LASER_HSV_UPPER, Config.SIMPLE_LASER_BRIGHTNESS_THRESHOLD, 10)
+    for H, W, B in ((37, 70, 5), (64, 129, 3), (90, 64, 9)):
+        frames = [_blob_image(rng, H, W) for _ in range(B)]
+        frames[1][...] = 0                                           # a frame without anything
+        ex = SimpleLaserExtractor(*args)
+        got = ex.extract_batch(frames)
+        want = [SimpleLaserExtractor(*args).extract_centerline(f) for f in frames]
+        assert got == want and got[1] == [] and sum(len(g) for g in got) > 0
+        assert np.array_equal(np.array(got[0]).reshape(-1, 2), O.simple_extract(frames[0], *args))
+        dev = ex.extract_batch_device(torch.from_numpy(np.stack(frames)).cuda())
+        assert dev == want
+        assert ex.extract_centerline(frames[2]) == want[2]           # the batch handle on a single image
+    # the benchmark frames, batch 16; frames of different shapes fall back to single calls
+    S = _S()
+    frames = [S.stereo_pair(640, 360, 64, 300 + k)[0] for k in range(16)]
+    ex = SimpleLaserExtractor(Config.SIMPLE_LASER_HSV_LOWER, Config.SIMPLE_LASER_HSV_UPPER, 200, 50)
+    got = ex.extract_batch(frames)
+    assert all(len(g) > 100 for g in got) and got[5] == SimpleLaserExtractor(Config.SIMPLE_LASER_HSV_LOWER, Config.SIMPLE_LASER_HSV_UPPER, 200, 50).extract_centerline(frames[5])
+    mixed = ex.extract_batch([frames[0], frames[1][:200]])
+    assert mixed[0] == got[0] and len(mixed[1]) > 50 and ex.extract_batch([]) == []
+    with pytest.raises(Exception):
+        N = __import__("laser_3d_reconstruction_amd._native", fromlist=["x"])
+        N.check(N.lib.l3d_simple_extract_batch_device(ex._h, None, 640, 360, 17, None, None, 200, 50.0, None, None, None), "batch beyond the handle")
+
+
 def _rig():
     K1 = np.array([[208.896, 0, 166.314], [0, 209.510, 131.166], [0, 0, 1]])
     K2 = np.array([[209.155, 0, 174.016], [0, 209.931, 133.061], [0, 0, 1]])
