@@ -18,8 +18,10 @@ namespace l3d {
 template <int NP, bool TONLY>
 struct SegLen {
     // TONLY prefetches three operands per column.  The longer segments fit the registers only when the next segment is
-    // requested late, a few columns at a time (LateFetch below): 16 columns with 4 words a lane, 8 with 5 or 6.
-    static constexpr int value = (NP == 4 && TONLY) ? 16 : ((NP <= 2 && !TONLY) || ((NP == 5 || NP == 6) && TONLY)) ? 8 : 4;
+    // requested late, a few columns at a time (LateFetch below): 16 columns with 3 or 4 words a lane, 8 with 5 or 6.
+    // (3 words a lane = 96 disparities on 16 lanes, the shape of single-frame handles: 3.27 -> 2.97 ms per 128 pairs
+    // against 4-column segments; batches of that shape run on 8 lanes with 6 words and 8-column segments, 2.62 ms.)
+    static constexpr int value = ((NP == 4 || NP == 3) && TONLY) ? 16 : ((NP <= 2 && !TONLY) || ((NP == 5 || NP == 6) && TONLY)) ? 8 : 4;
 };
 
 // Whether the second sweep requests the next segment from inside the current one, in two halves (after the left -> right
