@@ -1026,6 +1026,7 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
     __shared__ int cnt[STH * ST];   // at roots: pixel count, bit 31 = touches a shared tile edge
     __shared__ short dv[STH * ST];
     __shared__ unsigned long long rowL[STH]; // bit x: pixel x joins its left neighbour
+    __shared__ unsigned long long rowD[STH]; // bit x: pixel x joins the pixel below it
     __shared__ int plist[256];
     __shared__ int pn, pbase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1042,6 +1043,11 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         const int gy = ty0 + wv * (STH / 4) + rr;
         vrow[rr] = (gx < W && gy < H) ? (int)disp[img + (size_t)gy * W + gx] : newVal;
     }
+    // A tile whose rows are one run each and whose adjacent rows join somewhere is one component (most tiles of a dense
+    // disparity map): when that component is larger than maxSize nothing in the tile can be erased and nothing is pending.
+    const int wvalid = min(ST, W - tx0), hvalid = min(STH, H - ty0);
+    const unsigned long long one_run = ((wvalid == 64) ? ~0ull : ((1ull << wvalid) - 1ull)) & ~1ull;
+    bool plain = true;
 #pragma unroll
     for (int rr = 0; rr < STH / 4; rr++) {
         const int y = wv * (STH / 4) + rr, idx = y * ST + lane;
@@ -1051,6 +1057,7 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         const bool joinL = valid && lane > 0 && vl != newVal && abs(v - vl) <= maxDiff;
         const unsigned long long mL = __ballot(joinL);
         if (lane == 0) rowL[y] = mL;
+        if (y < hvalid) plain = plain && mL == one_run && (__ballot(valid) & 1ull);
         const int head = 63 - __clzll((long long)(~mL & upto)); // bit 0 of ~mL is always set
         dv[idx] = (short)v;
         lab[idx] = valid ? y * ST + head : -1;
@@ -1063,6 +1070,25 @@ __global__ void __launch_bounds__(256) k_speckle_tile(int16_t *__restrict__ disp
         const int v = dv[idx], vb = dv[idx + ST];
         const bool joinD = v != newVal && vb != newVal && abs(v - vb) <= maxDiff;
         const unsigned long long mD = __ballot(joinD);
+        if (lane == 0) rowD[y] = mD;
+        if (y + 1 < hvalid) plain = plain && mD != 0;
+    }
+    if (__syncthreads_and(plain) && wvalid * hvalid > maxSize) {
+        // the labels of the shared edges say "settled" (the pass over the edges reads them), the tile has nothing pending
+#pragma unroll
+        for (int rr = 0; rr < STH / 4; rr++) {
+            const int y = wv * (STH / 4) + rr, gy = ty0 + y;
+            if (gx >= W || gy >= H) continue;
+            const bool edge = (lane == 0 && tx0 > 0) || (lane == ST - 1 && gx + 1 < W) || (y == 0 && ty0 > 0) || (y == STH - 1 && gy + 1 < H);
+            if (edge) labels[img + (size_t)gy * W + gx] = -1;
+        }
+        if (tid == 0) tile_pending[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0;
+        return;
+    }
+    for (int rr = 0; rr < STH / 4; rr++) {
+        const int y = wv * (STH / 4) + rr, idx = y * ST + lane;
+        if (y + 1 >= STH) break;
+        const unsigned long long mD = rowD[y];
         // the join at x is implied by the join at x-1 when both rows continue from x-1 to x
         const unsigned long long need = mD & ~((mD << 1) & rowL[y] & rowL[y + 1]);
         if ((need >> lane) & 1ull) lds_union(lab, lab[idx], lab[idx + ST]);
