@@ -39,7 +39,7 @@ CONFIGS = {
     # what the reference's own constructor picks for a 640-px-wide eye (camera/single_usb_stereo_camera.py:239-282)
     "REFDEFAULT": (640, 360, 96, 7, True, 8000.0, 1.5),
 }
-DEFAULT_BATCH = {"C2": 256, "C3": 256, "C5": 64, "REFDEFAULT": 128}     # C3 / C5: +4 % over 128 / 32 (longer launches, shorter tails)
+DEFAULT_BATCH = {"C2": 256, "C3": 192, "C5": 64, "REFDEFAULT": 128}     # C3 / C5: +3 to 4 % over 128 / 32 (longer launches, shorter tails); C3 at 256 needs 240 of the 288 GB
 C4_STREAMS = 8
 C4_FRAMES_PER_RANK = 256     # a rank batches ceil(256 / streams it owns) consecutive frames of each of its streams per step
 ALSO_CONFIGS = ("C3", "C5", "REFDEFAULT")
@@ -264,7 +264,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times; the median run is reported")
-    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2 and C3, 64 for C5, 128 for REFDEFAULT; C4: 256 frames a rank over the streams it owns)")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step per GPU (default: 256 for C2, 192 for C3, 64 for C5, 128 for REFDEFAULT; C4: 256 frames a rank over the streams it owns)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--pipelines", type=int, default=2,
                     help="independent pipelines (matchers + buffers + streams) the steps alternate between, so that the tail of one "
