@@ -2,14 +2,15 @@
 through it) and ImprovedLaserSystem (test_improved_laser.py:23-207: left matcher only, laser pixels triangulated from
 the disparity map).
 
-LaserReconstructionSystem: ``initialize`` builds the same four components from the same ``Config`` knobs (main.py:51-162): the camera manager
-(without the Config, so the matcher follows the reference's width rule), the laser extractor chosen by
-``LASER_EXTRACTOR_TYPE``, a ``Reconstructor`` on the rectified intrinsics with ``LASER_PLANE_COEFFICIENTS`` /
-``USE_REFRACTION_CORRECTION``, and the point-cloud processor.  ``process_frame`` is main.py:164-189: frame -> rectified
-left image + depth map -> laser centre line -> 3-D points through the depth map -> rows without NaN appended to
-``point_cloud``.  Between those stages nothing leaves the device here: the combined camera frame is uploaded once, the
-extractor reads the rectified left image where the remap kernel left it, the back-projection reads the depth map where
-the depth kernel left it, and the three return values plus the new 3-D points are downloaded at the end.
+LaserReconstructionSystem: ``initialize`` builds the same four components from the same ``Config`` knobs
+(main.py:51-162): the camera manager (without the Config, so the matcher follows the reference's width rule), the laser
+extractor chosen by ``LASER_EXTRACTOR_TYPE``, a ``Reconstructor`` on the rectified intrinsics with
+``LASER_PLANE_COEFFICIENTS`` / ``USE_REFRACTION_CORRECTION``, and the point-cloud processor.  ``process_frame`` is
+main.py:164-189: frame -> rectified left image + depth map -> laser centre line -> 3-D points through the depth map ->
+rows without NaN appended to ``point_cloud``.  Between those stages nothing leaves the device here: the combined camera
+frame is uploaded once, the extractor reads the rectified left image where the remap kernel left it (the Simple
+extractor on a stream of its own, beside the matchers), the back-projection reads the depth map where the depth kernel
+left it, and the three return values plus the new 3-D points are downloaded at the end.
 
 Differences a caller can see: frames come from ``frame_source`` (an object with ``isOpened() / read() / release()``;
 camera capture is outside the accelerated path); the console window of ``run_realtime`` (cv2.imshow, key handling:
