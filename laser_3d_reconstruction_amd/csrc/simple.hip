@@ -227,12 +227,15 @@ __global__ void __launch_bounds__(256) k_contour_area(const uint8_t *__restrict_
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const bool inside = px[k] >= 0 && px[k] < W && py[k] >= 0 && py[k] < H;
-        const int idx = inside ? py[k] * W + px[k] : 0;
-        in[k] = inside && mask[idx] != 0;
-        lb[k] = inside ? lab[idx] : outer;
+        in[k] = inside && mask[inside ? py[k] * W + px[k] : 0] != 0;
         cnt += in[k];
     }
-    if (cnt == 0 || cnt == 4) return;
+    if (cnt == 0 || cnt == 4) return;      // no border passes through the cell (nearly all cells: the labels are not read)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool inside = px[k] >= 0 && px[k] < W && py[k] >= 0 && py[k] < H;
+        lb[k] = inside ? lab[py[k] * W + px[k]] : outer;
+    }
     // foreground pixels 4-adjacent to the outside background mark their component (pairs a-b, a-c, b-d, c-d)
     const int pa[4] = {0, 0, 1, 2}, pb[4] = {1, 2, 3, 3};
 #pragma unroll
